@@ -1,0 +1,165 @@
+/* quadgym.h -- C ABI of the MI355X-native batched quadruped simulator.
+ *
+ * This is the drop-in boundary for the one hot path of antopio26/quadruped-gym:
+ * QuadrupedEnv.step() / reset() (src/envs/quadruped.py:115-182) and the four
+ * call sites where that file hands the arithmetic to the third-party `mujoco`
+ * package (src/envs/quadruped.py:59,60,120,165).  The reference has no FFI of
+ * its own (it is plain Python over the mujoco bindings); each entry point below
+ * names the reference call it replaces.  Bindings: ctypes stub in INTEGRATION.md.
+ *
+ * Conventions: extern "C", opaque handle, int status (0 = ok, <0 = error, text
+ * from qg_last_error()), no exceptions cross the boundary, caller owns every
+ * buffer it passes, the library owns the per-env device state.  One handle is
+ * bound to one GPU; calls on a handle are not re-entrant.  There is NO CPU
+ * backend: every compute entry point fails with QG_ERR_DEVICE when no HIP device
+ * is usable.
+ *
+ * Layouts at the boundary (row-major, env-major -- what NumPy / torch hand over):
+ *   actions  [n_envs][12] f32      obs   [n_envs][obs_dim] f32
+ *   reward   [n_envs] f32          done  [n_envs] u8
+ *   reward_components [n_envs][3] f32  (forward, control_cost, alive)
+ *   packed   [n_envs][obs_dim + 2] f32 (obs, reward, done as 0/1) -- one buffer
+ *            for the per-step RCCL gather.
+ * State arrays (qg_get_state / qg_set_state): qpos [n][19], qvel [n][18],
+ * act [n][12], ctrl [n][12] f32 and nstep [n] i32 (physics substeps since
+ * reset; data.time = nstep * timestep).
+ */
+#ifndef QUADGYM_H
+#define QUADGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QG_NBODY 13      /* FRAME + 4 x (fema, shin, foot)      quadruped.xml:62-142 */
+#define QG_NLEG 4
+#define QG_NJNT 12       /* hinge joints = actuators            quadruped.xml:156-172 */
+#define QG_NQ 19         /* 3 pos + 4 quat + 12 hinge */
+#define QG_NV 18
+#define QG_NU 12
+#define QG_NSENSOR 33    /* model.nsensordata                   quadruped.xml:174-217 */
+#define QG_MAXCP 12      /* contact sample points per body (table width) */
+#define QG_NREWARD 3
+
+/* status codes */
+#define QG_OK 0
+#define QG_ERR_ARG (-1)
+#define QG_ERR_DEVICE (-2)
+#define QG_ERR_ALLOC (-3)
+#define QG_ERR_LAUNCH (-4)
+
+/* observation packs (qg_task.obs_mode) */
+#define QG_OBS_FULL 0    /* the 33-value sensordata of quadruped.py:141-143 */
+#define QG_OBS_IMU 1     /* jointpos 12 + accel 3 + gyro 3 + velocimeter 3 = 21 (BASELINE config 5) */
+
+/* qg_reset flags */
+#define QG_RESET_RANDOM_YAW 1u   /* walking_quad.py:68-75: qpos[3:7] = [cos a/2, 0, 0, sin a/2], a ~ U(0, 2 pi) */
+
+/* Robot constants: what mujoco.MjModel.from_xml_path (quadruped.py:59) compiles
+ * out of scene.xml.  Topology is fixed (body 0 = FRAME with the free joint, body
+ * 1+3k+{0,1,2} = fema/shin/foot of leg k, joint j drives body j+1); numbers are
+ * data.  Units SI, angles in radians, quaternions (w,x,y,z). */
+typedef struct qg_model {
+    double timestep;                       /* 0.002 (engine default, quadruped.xml:4 sets none) */
+    double gravity[3];
+    int32_t body_parent[QG_NBODY];         /* -1 for FRAME */
+    double body_pos[QG_NBODY][3];          /* body frame in the parent body frame */
+    double body_quat[QG_NBODY][4];
+    double body_mass[QG_NBODY];
+    double body_ipos[QG_NBODY][3];         /* centre of mass in the body frame */
+    double body_inertia[QG_NBODY][6];      /* xx yy zz xy xz yz about the COM, body axes */
+    double jnt_axis[QG_NJNT][3];           /* in the child body frame; anchor = body origin */
+    double jnt_ref[QG_NJNT];               /* qpos0 of the hinge; rotation applied = qpos - ref */
+    double jnt_range[QG_NJNT][2];
+    double jnt_damping[QG_NJNT];
+    double jnt_armature[QG_NJNT];
+    double free_damping;                   /* applies to all 6 base DoFs (childclass, quadruped.xml:9,62-63) */
+    double free_armature;
+    double act_kp[QG_NU], act_kv[QG_NU], act_gear[QG_NU], act_timeconst[QG_NU];
+    double act_ctrlrange[QG_NU][2], act_forcerange[QG_NU][2];
+    double limit_stiffness, limit_damping; /* soft joint limits (N m/rad, N m s/rad) */
+    int32_t ncp[QG_NBODY];                 /* must be 12 for FRAME, 8 for every link */
+    double cp[QG_NBODY][QG_MAXCP][3];      /* contact sample points, body frame */
+    double contact_stiffness;              /* N/m per sample point */
+    double contact_damping;                /* N s/m per body in contact (implicit) */
+    double contact_margin;                 /* contact starts at this height */
+    double contact_friction;               /* Coulomb mu */
+    double qpos0[QG_NQ];                   /* what mj_resetData restores (quadruped.py:120) */
+} qg_model;
+
+/* Task constants: QuadrupedEnv's constructor arguments and the README reward /
+ * termination set (quadruped.py:40-52,97-100,149-151; README.md:64-90). */
+typedef struct qg_task {
+    int32_t frame_skip;        /* quadruped.py:44, default 4 */
+    double max_time;           /* quadruped.py:43, default 10.0; reported as `terminated` */
+    int32_t use_time_limit;    /* use_default_termination, quadruped.py:52,99-100 */
+    int32_t use_fall;          /* README.md:86-89 */
+    double fall_height;        /* README literal 0.2; the base starts at 0.13 (quadruped.xml:62) */
+    double w_forward;          /* reward = w_forward*qvel[0] + w_ctrl*sum(ctrl^2) + alive; README.md:65-72 */
+    double w_ctrl;             /* -0.1 */
+    double alive_bonus;        /* 1.0 */
+    int32_t obs_mode;          /* QG_OBS_FULL | QG_OBS_IMU */
+    int32_t sensor_lag;        /* 1 = sensors describe the start of the last substep (mj_step order) */
+    int32_t auto_reset;        /* 1 = envs that finish are reset inside the step (VecEnv semantics) */
+    uint32_t reset_flags;      /* QG_RESET_* applied by auto-reset */
+    double default_ctrl[QG_NU];/* quadruped.py:124: [0, 0, -0.5] * 4 */
+} qg_task;
+
+typedef struct qg_sim qg_sim;  /* opaque */
+
+const char *qg_version(void);
+const char *qg_last_error(void);
+
+/* Fill with the constants compiled from the reference model (include/qg_model_data.h). */
+int qg_default_model(qg_model *out);
+int qg_default_task(qg_task *out);
+
+/* Substep count at which `data.time >= max_time` first holds when time is
+ * accumulated as the reference's engine does it (f64, time += timestep per
+ * substep); quadruped.py:149-151. */
+int64_t qg_time_limit_substeps(double timestep, double max_time);
+
+/* Replaces MjModel.from_xml_path + MjData (quadruped.py:59-60).  `env_index_base`
+ * is the global index of this handle's env 0 (shards of one batch get disjoint
+ * ranges so per-env random streams do not depend on the sharding). */
+int qg_create(int32_t n_envs, int32_t device_id, const qg_model *model, const qg_task *task,
+              uint64_t env_index_base, qg_sim **out);
+int qg_destroy(qg_sim *sim);
+int qg_num_envs(const qg_sim *sim);
+int qg_obs_dim(const qg_sim *sim);
+
+/* Replaces QuadrupedEnv.reset (quadruped.py:115-139): mj_resetData, time = 0,
+ * ctrl = default.  mask == NULL resets every env, else only mask[i] != 0
+ * (host pointer, n_envs bytes).  The first observation is all zeros, as in the
+ * reference (no mj_forward after mj_resetData). */
+int qg_reset(qg_sim *sim, const uint8_t *mask, uint64_t seed, uint32_t flags);
+
+/* Replaces QuadrupedEnv.step (quadruped.py:153-182) for the whole batch: clip to
+ * [-1, 1], frame_skip x {ctrl = action; mj_step}, sensor pack, rewards,
+ * terminations.  Host-pointer form (copies in and out, synchronous). */
+int qg_step(qg_sim *sim, const float *actions, float *obs, float *reward, uint8_t *done,
+            float *reward_components /* nullable */);
+
+/* Device-pointer forms: every pointer is device memory on the handle's GPU,
+ * `stream` is a hipStream_t (NULL = default stream); asynchronous. */
+int qg_step_device(qg_sim *sim, const float *actions, float *obs, float *reward, uint8_t *done,
+                   float *reward_components /* nullable */, void *stream);
+int qg_step_device_packed(qg_sim *sim, const float *actions, float *packed, void *stream);
+
+/* Snapshot / restore of data.qpos, qvel, act, ctrl and the substep counter
+ * (host pointers; any may be NULL).  Used by the parity tests and checkpoints. */
+int qg_get_state(qg_sim *sim, float *qpos, float *qvel, float *act, float *ctrl, int32_t *nstep);
+int qg_set_state(qg_sim *sim, const float *qpos, const float *qvel, const float *act, const float *ctrl,
+                 const int32_t *nstep);
+
+/* Time the step kernel alone: `iters` launches back to back on the handle's own
+ * stream bracketed by HIP events on that stream; returns the mean milliseconds
+ * per launch in *ms_per_launch.  State advances `iters` env-steps. */
+int qg_time_step_kernel(qg_sim *sim, const float *d_actions, float *d_packed, int32_t iters, float *ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADGYM_H */

@@ -1,0 +1,211 @@
+"""ctypes wrapper of the CPU oracle (``oracle/qg_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` -- never by the product package.
+The physics parity of the oracle itself is UNPINNED (no MuJoCo offline, no
+reference fixtures); it is pinned by the known-answer tests in
+``tests/test_oracle_physics.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from quadruped_gym_amd._abi import NQ, NV, NU, NBODY, NSENSOR, QgModel, QgTask
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libqgoracle.so")
+
+
+class Env(C.Structure):
+    _fields_ = [("qpos", C.c_double * NQ), ("qvel", C.c_double * NV), ("act", C.c_double * NU),
+                ("ctrl", C.c_double * NU), ("nstep", C.c_int32)]
+
+
+class Diag(C.Structure):
+    _fields_ = [("M", C.c_double * (NV * NV)), ("A", C.c_double * (NV * NV)), ("bias", C.c_double * NV),
+                ("f_passive", C.c_double * NV), ("f_act", C.c_double * NV), ("f_limit", C.c_double * NV),
+                ("f_contact", C.c_double * NV), ("qacc", C.c_double * NV), ("act_force", C.c_double * NU),
+                ("contact_W", C.c_double * NBODY), ("contact_F", (C.c_double * 3) * NBODY),
+                ("contact_P", (C.c_double * 3) * NBODY)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "qg_oracle.c")
+    deps = [src, os.path.join(_HERE, "..", "include", "quadgym.h"), os.path.join(_HERE, "..", "include", "qg_model_data.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+        subprocess.run(["make", "-C", _HERE, "-B", "libqgoracle.so"], check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        L.qgo_uniform.restype = C.c_double
+        L.qgo_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.qgo_time_limit_substeps.restype = C.c_int64
+        L.qgo_time_limit_substeps.argtypes = [C.c_double, C.c_double]
+        L.qgo_reset.argtypes = [C.POINTER(QgModel), C.POINTER(QgTask), C.POINTER(Env), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.qgo_substep.argtypes = [C.POINTER(QgModel), C.POINTER(Env), dp, dp, C.POINTER(Diag)]
+        L.qgo_step.argtypes = [C.POINTER(QgModel), C.POINTER(QgTask), C.POINTER(Env), dp, C.c_int64, dp, dp,
+                               C.POINTER(C.c_int32), dp]
+        L.qgo_step_batch.argtypes = [C.POINTER(QgModel), C.POINTER(QgTask), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert L.qgo_sizeof_env() == C.sizeof(Env), (L.qgo_sizeof_env(), C.sizeof(Env))
+        assert L.qgo_sizeof_diag() == C.sizeof(Diag)
+        assert L.qgo_sizeof_model() == C.sizeof(QgModel), (L.qgo_sizeof_model(), C.sizeof(QgModel))
+        assert L.qgo_sizeof_task() == C.sizeof(QgTask), (L.qgo_sizeof_task(), C.sizeof(QgTask))
+        _lib = L
+    return _lib
+
+
+def default_model() -> QgModel:
+    m = QgModel()
+    lib().qgo_default_model(C.byref(m))
+    return m
+
+
+def default_task() -> QgTask:
+    t = QgTask()
+    lib().qgo_default_task(C.byref(t))
+    return t
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _arr(x, n):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    assert a.size == n, (a.shape, n)
+    return a
+
+
+def time_limit_substeps(timestep, max_time) -> int:
+    return int(lib().qgo_time_limit_substeps(timestep, max_time))
+
+
+def uniform(seed, env_index, counter) -> float:
+    return float(lib().qgo_uniform(seed, env_index, counter))
+
+
+def mass_matrix(model, qpos):
+    M = np.zeros((NV, NV))
+    lib().qgo_mass_matrix(C.byref(model), _dp(_arr(qpos, NQ)), _dp(M))
+    return M
+
+
+def rne(model, qpos, qvel, qacc=None):
+    tau = np.zeros(NV)
+    qa = None if qacc is None else _dp(_arr(qacc, NV))
+    lib().qgo_rne(C.byref(model), _dp(_arr(qpos, NQ)), _dp(_arr(qvel, NV)), qa, _dp(tau))
+    return tau
+
+
+def kinematics(model, qpos):
+    xpos = np.zeros((NBODY, 3)); xmat = np.zeros((NBODY, 3, 3)); xcom = np.zeros((NBODY, 3))
+    lib().qgo_kinematics(C.byref(model), _dp(_arr(qpos, NQ)), _dp(xpos), _dp(xmat), _dp(xcom))
+    return xpos, xmat, xcom
+
+
+def energy(model, qpos, qvel):
+    k, p = C.c_double(), C.c_double()
+    lib().qgo_energy(C.byref(model), _dp(_arr(qpos, NQ)), _dp(_arr(qvel, NV)), C.byref(k), C.byref(p))
+    return k.value, p.value
+
+
+def momentum(model, qpos, qvel):
+    lin, ang = np.zeros(3), np.zeros(3)
+    lib().qgo_momentum(C.byref(model), _dp(_arr(qpos, NQ)), _dp(_arr(qvel, NV)), _dp(lin), _dp(ang))
+    return lin, ang
+
+
+def make_env(qpos, qvel=None, act=None, ctrl=None, nstep=0) -> Env:
+    e = Env()
+    e.qpos[:] = list(np.asarray(qpos, float))
+    e.qvel[:] = list(np.zeros(NV) if qvel is None else np.asarray(qvel, float))
+    e.act[:] = list(np.zeros(NU) if act is None else np.asarray(act, float))
+    e.ctrl[:] = list(np.zeros(NU) if ctrl is None else np.asarray(ctrl, float))
+    e.nstep = int(nstep)
+    return e
+
+
+def reset(model, task, seed=0, env_index=0, counter=0, flags=0) -> Env:
+    e = Env()
+    lib().qgo_reset(C.byref(model), C.byref(task), C.byref(e), seed, env_index, counter, flags)
+    return e
+
+
+def substep(model, env, ctrl, want_sensors=False, want_diag=False):
+    sens = np.zeros(NSENSOR) if want_sensors else None
+    dg = Diag() if want_diag else None
+    rc = lib().qgo_substep(C.byref(model), C.byref(env), _dp(_arr(ctrl, NU)), _dp(sens) if want_sensors else None,
+                           C.byref(dg) if want_diag else None)
+    if rc != 0:
+        raise FloatingPointError("oracle linear solve failed")
+    return sens, dg
+
+
+def step(model, task, env, action, limit_substeps=None):
+    if limit_substeps is None:
+        limit_substeps = time_limit_substeps(model.timestep, task.max_time)
+    od = 21 if task.obs_mode == 1 else NSENSOR
+    obs = np.zeros(od); comps = np.zeros(3)
+    rew = C.c_double(); done = C.c_int32()
+    rc = lib().qgo_step(C.byref(model), C.byref(task), C.byref(env), _dp(_arr(action, NU)), limit_substeps, _dp(obs),
+                        C.byref(rew), C.byref(done), _dp(comps))
+    if rc != 0:
+        raise FloatingPointError("oracle linear solve failed")
+    return obs, rew.value, bool(done.value), comps
+
+
+class Batch:
+    """n independent oracle envs stepped in C (env-major arrays)."""
+
+    def __init__(self, model, task, n):
+        self.model, self.task, self.n = model, task, n
+        self.envs = (Env * n)()
+        self.limit = time_limit_substeps(model.timestep, task.max_time)
+        self.od = 21 if task.obs_mode == 1 else NSENSOR
+
+    def reset(self, seed=0, env_index_base=0, counter=0, flags=0, mask=None):
+        for i in range(self.n):
+            if mask is None or mask[i]:
+                lib().qgo_reset(C.byref(self.model), C.byref(self.task), C.byref(self.envs[i]), seed,
+                                env_index_base + i, counter, flags)
+
+    def set_state(self, qpos, qvel, act, ctrl=None, nstep=None):
+        for i in range(self.n):
+            e = self.envs[i]
+            e.qpos[:] = list(map(float, qpos[i])); e.qvel[:] = list(map(float, qvel[i])); e.act[:] = list(map(float, act[i]))
+            if ctrl is not None:
+                e.ctrl[:] = list(map(float, ctrl[i]))
+            if nstep is not None:
+                e.nstep = int(nstep[i])
+
+    def get_state(self):
+        a = np.frombuffer(self.envs, dtype=np.uint8).reshape(self.n, C.sizeof(Env))
+        f = a[:, : 8 * (NQ + NV + NU + NU)].copy().view(np.float64).reshape(self.n, -1)
+        nstep = np.array([self.envs[i].nstep for i in range(self.n)], dtype=np.int32)
+        return f[:, :NQ].copy(), f[:, NQ:NQ + NV].copy(), f[:, NQ + NV:NQ + NV + NU].copy(), f[:, NQ + NV + NU:].copy(), nstep
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        assert a.shape == (self.n, NU)
+        obs = np.zeros((self.n, self.od)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.int32)
+        comps = np.zeros((self.n, 3))
+        rc = lib().qgo_step_batch(C.byref(self.model), C.byref(self.task), C.addressof(self.envs), self.n,
+                                  a.ctypes.data, self.limit, obs.ctypes.data, rew.ctypes.data, done.ctypes.data,
+                                  comps.ctypes.data)
+        if rc != 0:
+            raise FloatingPointError(f"oracle linear solve failed (env {-rc - 1})")
+        return obs, rew, done.astype(bool), comps

@@ -1,0 +1,150 @@
+"""ctypes mirrors of the C structs in ``include/quadgym.h`` and the loader of
+``libquadgym.so`` (the HIP pipeline behind the C ABI).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+usable, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+NBODY, NJNT, NQ, NV, NU, NSENSOR, MAXCP, NREWARD = 13, 12, 19, 18, 12, 33, 12, 3
+OBS_FULL, OBS_IMU = 0, 1
+RESET_RANDOM_YAW = 1
+OBS_DIM = {OBS_FULL: 33, OBS_IMU: 21}
+
+
+class QgModel(C.Structure):
+    _fields_ = [
+        ("timestep", C.c_double),
+        ("gravity", C.c_double * 3),
+        ("body_parent", C.c_int32 * NBODY),
+        ("body_pos", (C.c_double * 3) * NBODY),
+        ("body_quat", (C.c_double * 4) * NBODY),
+        ("body_mass", C.c_double * NBODY),
+        ("body_ipos", (C.c_double * 3) * NBODY),
+        ("body_inertia", (C.c_double * 6) * NBODY),
+        ("jnt_axis", (C.c_double * 3) * NJNT),
+        ("jnt_ref", C.c_double * NJNT),
+        ("jnt_range", (C.c_double * 2) * NJNT),
+        ("jnt_damping", C.c_double * NJNT),
+        ("jnt_armature", C.c_double * NJNT),
+        ("free_damping", C.c_double),
+        ("free_armature", C.c_double),
+        ("act_kp", C.c_double * NU),
+        ("act_kv", C.c_double * NU),
+        ("act_gear", C.c_double * NU),
+        ("act_timeconst", C.c_double * NU),
+        ("act_ctrlrange", (C.c_double * 2) * NU),
+        ("act_forcerange", (C.c_double * 2) * NU),
+        ("limit_stiffness", C.c_double),
+        ("limit_damping", C.c_double),
+        ("ncp", C.c_int32 * NBODY),
+        ("cp", ((C.c_double * 3) * MAXCP) * NBODY),
+        ("contact_stiffness", C.c_double),
+        ("contact_damping", C.c_double),
+        ("contact_margin", C.c_double),
+        ("contact_friction", C.c_double),
+        ("qpos0", C.c_double * NQ),
+    ]
+
+
+class QgTask(C.Structure):
+    _fields_ = [
+        ("frame_skip", C.c_int32),
+        ("max_time", C.c_double),
+        ("use_time_limit", C.c_int32),
+        ("use_fall", C.c_int32),
+        ("fall_height", C.c_double),
+        ("w_forward", C.c_double),
+        ("w_ctrl", C.c_double),
+        ("alive_bonus", C.c_double),
+        ("obs_mode", C.c_int32),
+        ("sensor_lag", C.c_int32),
+        ("auto_reset", C.c_int32),
+        ("reset_flags", C.c_uint32),
+        ("default_ctrl", C.c_double * NU),
+    ]
+
+
+def package_dir() -> str:
+    return os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path() -> str:
+    return os.path.join(package_dir(), "csrc", "libquadgym.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load ``libquadgym.so`` and declare the prototypes of every exported entry
+    point (``include/quadgym.h``).  Raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C quadruped-gym_amd/csrc`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, u8p, fp, i32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    lib.qg_version.restype = C.c_char_p
+    lib.qg_version.argtypes = []
+    lib.qg_last_error.restype = C.c_char_p
+    lib.qg_last_error.argtypes = []
+    lib.qg_default_model.argtypes = [C.POINTER(QgModel)]
+    lib.qg_default_task.argtypes = [C.POINTER(QgTask)]
+    lib.qg_time_limit_substeps.restype = C.c_int64
+    lib.qg_time_limit_substeps.argtypes = [C.c_double, C.c_double]
+    lib.qg_create.argtypes = [C.c_int32, C.c_int32, C.POINTER(QgModel), C.POINTER(QgTask), C.c_uint64, C.POINTER(vp)]
+    lib.qg_destroy.argtypes = [vp]
+    lib.qg_num_envs.argtypes = [vp]
+    lib.qg_obs_dim.argtypes = [vp]
+    lib.qg_reset.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+    lib.qg_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.qg_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.qg_step_device_packed.argtypes = [vp, vp, vp, vp]
+    lib.qg_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.qg_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.qg_time_step_kernel.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+# every symbol include/quadgym.h declares
+EXPORTS = (
+    "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
+    "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
+    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel",
+)
+
+
+class QuadGymError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = load_library().qg_last_error().decode("utf-8", "replace")
+        raise QuadGymError(f"{what} failed ({status}): {msg}")
+
+
+def default_model() -> QgModel:
+    m = QgModel()
+    check(load_library().qg_default_model(C.byref(m)), "qg_default_model")
+    return m
+
+
+def default_task() -> QgTask:
+    t = QgTask()
+    check(load_library().qg_default_task(C.byref(t)), "qg_default_task")
+    return t
