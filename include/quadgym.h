@@ -159,6 +159,10 @@ int qg_set_state(qg_sim *sim, const float *qpos, const float *qvel, const float 
  * per launch in *ms_per_launch.  State advances `iters` env-steps. */
 int qg_time_step_kernel(qg_sim *sim, const float *d_actions, float *d_packed, int32_t iters, float *ms_per_launch);
 
+/* data.ctrl (the last env-clipped action, quadruped.py:164) is written back each step only
+ * while this is on (default on; bulk-throughput callers switch it off). */
+int qg_set_track_ctrl(qg_sim *sim, int32_t on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,7 @@ def load_library():
     lib.qg_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qg_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qg_time_step_kernel.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
+    lib.qg_set_track_ctrl.argtypes = [vp, C.c_int32]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
@@ -124,7 +125,7 @@ def load_library():
 EXPORTS = (
     "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
-    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel",
+    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl",
 )
 
 

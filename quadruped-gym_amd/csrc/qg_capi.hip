@@ -1,0 +1,419 @@
+// qg_capi.hip -- host side of the C ABI declared in include/quadgym.h.
+//
+// Owns the per-env device state (struct-of-arrays in HBM), converts the double-precision
+// model/task descriptions into the kernarg-sized single-precision tables the kernels read,
+// and launches the kernels of qg_kernels.hip.  There is no CPU code path: every compute
+// entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/quadgym.h"
+#include "../../include/qg_model_data.h"
+// the kernels are compiled in the same translation unit (one code object, no -fgpu-rdc)
+#include "qg_kernels.hip"
+
+struct qg_sim {
+    int32_t n;
+    int32_t device;
+    int32_t obs_dim;
+    qg_model model;
+    qg_task task;
+    KModel *d_model;
+    KTask *d_task;
+    KState st;
+    // staging for the host-pointer entry points
+    float *d_actions, *d_obs, *d_reward, *d_comps, *d_stage;
+    uint8_t *d_done, *d_mask;
+    hipStream_t stream;       // the library's own stream (host-pointer calls, timing)
+    hipEvent_t ev0, ev1;
+    uint64_t seed;
+    uint64_t env_index_base;
+    uint64_t step_index;
+    int32_t track_ctrl;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                                         \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(code, "%s: %s", #expr, hipGetErrorString(e_));            \
+    } while (0)
+
+extern "C" const char *qg_version(void) { return "quadgym 0.1.0 (gfx950)"; }
+extern "C" const char *qg_last_error(void) { return g_err; }
+
+extern "C" int qg_default_model(qg_model *out) {
+    if (!out) return fail(QG_ERR_ARG, "qg_default_model: null output");
+    static const qg_model def = QG_MODEL_DEFAULT_INIT;
+    *out = def;
+    return QG_OK;
+}
+
+extern "C" int qg_default_task(qg_task *out) {
+    if (!out) return fail(QG_ERR_ARG, "qg_default_task: null output");
+    memset(out, 0, sizeof *out);
+    out->frame_skip = 4;          // quadruped.py:44
+    out->max_time = 10.0;         // quadruped.py:43
+    out->use_time_limit = 1;      // quadruped.py:52
+    out->use_fall = 0;
+    out->fall_height = 0.2;       // README.md:87
+    out->w_forward = 1.0;         // README.md:65-72
+    out->w_ctrl = -0.1;
+    out->alive_bonus = 1.0;
+    out->obs_mode = QG_OBS_FULL;
+    out->sensor_lag = 1;
+    out->auto_reset = 0;
+    out->reset_flags = 0;
+    for (int i = 0; i < QG_NU; i++) out->default_ctrl[i] = (i % 3 == 2) ? -0.5 : 0.0;   // quadruped.py:124
+    return QG_OK;
+}
+
+extern "C" int64_t qg_time_limit_substeps(double timestep, double max_time) {
+    if (!(timestep > 0)) return -1;
+    double t = 0;
+    int64_t n = 0;
+    while (!(t >= max_time)) {     // quadruped.py:151 with the engine's `time += timestep`
+        t += timestep;
+        n++;
+        if (n >= INT32_MAX) break;
+    }
+    return n;
+}
+
+static void quat_to_rowmajor(const double q[4], float R[9]) {
+    double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+    R[0] = (float)(1 - 2 * (y * y + z * z)); R[1] = (float)(2 * (x * y - w * z));     R[2] = (float)(2 * (x * z + w * y));
+    R[3] = (float)(2 * (x * y + w * z));     R[4] = (float)(1 - 2 * (x * x + z * z)); R[5] = (float)(2 * (y * z - w * x));
+    R[6] = (float)(2 * (x * z - w * y));     R[7] = (float)(2 * (y * z + w * x));     R[8] = (float)(1 - 2 * (x * x + y * y));
+}
+
+static int build_tables(const qg_model *m, const qg_task *t, KModel *km, KTask *kt) {
+    if (!(m->timestep > 0)) return fail(QG_ERR_ARG, "model.timestep must be positive");
+    if (m->body_parent[0] != -1) return fail(QG_ERR_ARG, "body 0 must be the free-floating FRAME");
+    if (m->ncp[0] != QGK_CP_FRAME) return fail(QG_ERR_ARG, "FRAME must carry %d contact points", QGK_CP_FRAME);
+    for (int b = 1; b < QG_NBODY; b++) {
+        int expect = ((b - 1) % 3 == 0) ? 0 : b - 1;
+        if (m->body_parent[b] != expect) return fail(QG_ERR_ARG, "body %d: parent %d, expected %d (4 chains of 3 links)", b, m->body_parent[b], expect);
+        if (m->ncp[b] != QGK_CP_LINK) return fail(QG_ERR_ARG, "body %d must carry %d contact points", b, QGK_CP_LINK);
+        const double *ax = m->jnt_axis[b - 1];
+        double an = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+        if (!(std::fabs(ax[0]) < 1e-12 * an && std::fabs(ax[1]) < 1e-12 * an && ax[2] > 0))
+            return fail(QG_ERR_ARG, "joint %d: the kernels assume the hinge axis is the link's +z (quadruped.xml:9)", b - 1);
+    }
+    if (t->frame_skip < 1) return fail(QG_ERR_ARG, "task.frame_skip must be >= 1");
+    if (t->obs_mode != QG_OBS_FULL && t->obs_mode != QG_OBS_IMU) return fail(QG_ERR_ARG, "task.obs_mode invalid");
+
+    memset(km, 0, sizeof *km);
+    km->h = (float)m->timestep;
+    for (int i = 0; i < 3; i++) km->g[i] = (float)m->gravity[i];
+    // FRAME: rigid inertia about its own origin
+    {
+        double ms = m->body_mass[0];
+        const double *c = m->body_ipos[0], *I = m->body_inertia[0];
+        double cc = c[0] * c[0] + c[1] * c[1] + c[2] * c[2];
+        km->m0 = (float)ms;
+        for (int i = 0; i < 3; i++) km->h0[i] = (float)(ms * c[i]);
+        km->I0[0] = (float)(I[0] + ms * (cc - c[0] * c[0]));
+        km->I0[1] = (float)(I[1] + ms * (cc - c[1] * c[1]));
+        km->I0[2] = (float)(I[2] + ms * (cc - c[2] * c[2]));
+        km->I0[3] = (float)(I[3] - ms * c[0] * c[1]);
+        km->I0[4] = (float)(I[4] - ms * c[0] * c[2]);
+        km->I0[5] = (float)(I[5] - ms * c[1] * c[2]);
+        for (int i = 0; i < QGK_CP_FRAME; i++)
+            for (int d = 0; d < 3; d++) km->cp0[i][d] = (float)m->cp[0][i][d];
+    }
+    km->free_damping = (float)m->free_damping;
+    km->free_armature = (float)m->free_armature;
+    km->contact_k = (float)m->contact_stiffness;
+    km->contact_c = (float)m->contact_damping;
+    km->contact_margin = (float)m->contact_margin;
+    km->contact_mu = (float)m->contact_friction;
+    km->limit_k = (float)m->limit_stiffness;
+    km->limit_b = (float)m->limit_damping;
+    for (int i = 0; i < QG_NQ; i++) km->qpos0[i] = (float)m->qpos0[i];
+    for (int j = 0; j < QGK_NLINK; j++) {
+        KLink &L = km->link[j];
+        int b = j + 1;
+        for (int d = 0; d < 3; d++) { L.pos[d] = (float)m->body_pos[b][d]; L.ipos[d] = (float)m->body_ipos[b][d]; }
+        quat_to_rowmajor(m->body_quat[b], L.Q);
+        L.mass = (float)m->body_mass[b];
+        for (int d = 0; d < 6; d++) L.inertia[d] = (float)m->body_inertia[b][d];
+        for (int i = 0; i < QGK_CP_LINK; i++)
+            for (int d = 0; d < 3; d++) L.cp[i][d] = (float)m->cp[b][i][d];
+        L.ref = (float)m->jnt_ref[j];
+        L.lo = (float)m->jnt_range[j][0];
+        L.hi = (float)m->jnt_range[j][1];
+        L.damping = (float)m->jnt_damping[j];
+        L.armature = (float)m->jnt_armature[j];
+        L.kp = (float)m->act_kp[j];
+        L.kv = (float)m->act_kv[j];
+        L.gear = (float)m->act_gear[j];
+        L.ctrl_lo = (float)m->act_ctrlrange[j][0];
+        L.ctrl_hi = (float)m->act_ctrlrange[j][1];
+        L.force_lo = (float)m->act_forcerange[j][0];
+        L.force_hi = (float)m->act_forcerange[j][1];
+        double tau = m->act_timeconst[j];
+        L.act_decay = (float)(tau > 0 ? 1.0 - std::exp(-m->timestep / tau) : 1.0);   // filterexact
+    }
+
+    memset(kt, 0, sizeof *kt);
+    kt->frame_skip = t->frame_skip;
+    int64_t lim = t->use_time_limit ? qg_time_limit_substeps(m->timestep, t->max_time) : (int64_t)INT32_MAX;
+    kt->limit_substeps = (int32_t)(lim > INT32_MAX ? INT32_MAX : lim);
+    kt->use_fall = t->use_fall;
+    kt->fall_height = (float)t->fall_height;
+    kt->w_forward = (float)t->w_forward;
+    kt->w_ctrl = (float)t->w_ctrl;
+    kt->alive_bonus = (float)t->alive_bonus;
+    kt->obs_mode = t->obs_mode;
+    kt->sensor_lag = t->sensor_lag;
+    kt->auto_reset = t->auto_reset;
+    kt->reset_flags = t->reset_flags;
+    for (int i = 0; i < QG_NU; i++) kt->default_ctrl[i] = (float)t->default_ctrl[i];
+    return QG_OK;
+}
+
+extern "C" int qg_destroy(qg_sim *s) {
+    if (!s) return QG_OK;
+    (void)hipSetDevice(s->device);
+    void *ptrs[] = {s->d_model, s->d_task, s->st.qpos, s->st.qvel, s->st.act, s->st.ctrl, s->st.nstep, s->d_actions,
+                    s->d_obs,   s->d_reward, s->d_comps, s->d_stage, s->d_done, s->d_mask};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return QG_OK;
+}
+
+extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *model, const qg_task *task, uint64_t env_index_base,
+                         qg_sim **out) {
+    if (!out) return fail(QG_ERR_ARG, "qg_create: null output");
+    *out = nullptr;
+    if (n_envs < 1) return fail(QG_ERR_ARG, "qg_create: n_envs must be >= 1");
+    qg_model dm;
+    qg_task dt;
+    if (!model) { qg_default_model(&dm); model = &dm; }
+    if (!task) { qg_default_task(&dt); task = &dt; }
+    KModel km;
+    KTask kt;
+    int rc = build_tables(model, task, &km, &kt);
+    if (rc != QG_OK) return rc;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(QG_ERR_DEVICE, "no HIP device is available; quadgym has no CPU backend");
+    if (device_id < 0 || device_id >= ndev) return fail(QG_ERR_DEVICE, "device_id %d out of range (0..%d)", device_id, ndev - 1);
+    HIP_TRY(hipSetDevice(device_id), QG_ERR_DEVICE);
+
+    qg_sim *s = new (std::nothrow) qg_sim();
+    if (!s) return fail(QG_ERR_ALLOC, "out of host memory");
+    memset(s, 0, sizeof *s);
+    s->n = n_envs;
+    s->device = device_id;
+    s->obs_dim = task->obs_mode == QG_OBS_IMU ? 21 : QG_NSENSOR;
+    s->model = *model;
+    s->task = *task;
+    s->env_index_base = env_index_base;
+    s->track_ctrl = 1;
+    size_t n = (size_t)n_envs;
+#define ALLOC(ptr, bytes)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                \
+        if (e_ != hipSuccess) {                                                             \
+            qg_destroy(s);                                                                  \
+            return fail(QG_ERR_ALLOC, "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                                                   \
+    } while (0)
+    ALLOC(s->d_model, sizeof(KModel));
+    ALLOC(s->d_task, sizeof(KTask));
+    ALLOC(s->st.qpos, n * QG_NQ * sizeof(float));
+    ALLOC(s->st.qvel, n * QG_NV * sizeof(float));
+    ALLOC(s->st.act, n * QG_NU * sizeof(float));
+    ALLOC(s->st.ctrl, n * QG_NU * sizeof(float));
+    ALLOC(s->st.nstep, n * sizeof(int32_t));
+    ALLOC(s->d_actions, n * QG_NU * sizeof(float));
+    ALLOC(s->d_obs, n * (QG_NSENSOR + 2) * sizeof(float));
+    ALLOC(s->d_reward, n * sizeof(float));
+    ALLOC(s->d_comps, n * QG_NREWARD * sizeof(float));
+    ALLOC(s->d_stage, n * QG_NQ * sizeof(float));
+    ALLOC(s->d_done, n);
+    ALLOC(s->d_mask, n);
+#undef ALLOC
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&s->ev1);
+    if (e == hipSuccess) e = hipMemcpy(s->d_model, &km, sizeof km, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        qg_destroy(s);
+        return fail(QG_ERR_DEVICE, "device setup: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    rc = qg_reset(s, nullptr, 0, 0);
+    if (rc != QG_OK) {
+        qg_destroy(s);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+extern "C" int qg_num_envs(const qg_sim *s) { return s ? s->n : fail(QG_ERR_ARG, "null handle"); }
+extern "C" int qg_obs_dim(const qg_sim *s) { return s ? s->obs_dim : fail(QG_ERR_ARG, "null handle"); }
+
+extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t flags) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    s->seed = seed;
+    const uint8_t *dmask = nullptr;
+    if (mask) {
+        HIP_TRY(hipMemcpyAsync(s->d_mask, mask, (size_t)s->n, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
+        dmask = s->d_mask;
+    }
+    int threads = 256, blocks = (s->n + threads - 1) / threads;
+    hipLaunchKernelGGL(qg_reset_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->d_model, s->d_task, s->st, s->n, dmask, seed,
+                       s->env_index_base, s->step_index, flags);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_done, float *d_comps,
+                       float *d_packed, hipStream_t stream) {
+    KStepArgs P;
+    P.st = s->st;
+    P.n = s->n;
+    P.track_ctrl = s->track_ctrl;
+    P.actions = d_actions;
+    P.obs = d_obs;
+    P.reward = d_reward;
+    P.done = d_done;
+    P.comps = d_comps;
+    P.packed = d_packed;
+    P.seed = s->seed;
+    P.env_index_base = s->env_index_base;
+    P.step_index = s->step_index;
+    int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
+    hipLaunchKernelGGL(qg_step_kernel, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+    s->step_index++;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_step_kernel launch: %s", hipGetErrorString(e));
+    return QG_OK;
+}
+
+extern "C" int qg_step_device(qg_sim *s, const float *actions, float *obs, float *reward, uint8_t *done, float *comps, void *stream) {
+    if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step_device: null argument");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    return launch_step(s, actions, obs, reward, done, comps, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int qg_step_device_packed(qg_sim *s, const float *actions, float *packed, void *stream) {
+    if (!s || !actions || !packed) return fail(QG_ERR_ARG, "qg_step_device_packed: null argument");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    return launch_step(s, actions, nullptr, nullptr, nullptr, nullptr, packed, (hipStream_t)stream);
+}
+
+extern "C" int qg_step(qg_sim *s, const float *actions, float *obs, float *reward, uint8_t *done, float *comps) {
+    if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step: null argument");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    size_t n = (size_t)s->n;
+    HIP_TRY(hipMemcpyAsync(s->d_actions, actions, n * QG_NU * sizeof(float), hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
+    int rc = launch_step(s, s->d_actions, s->d_obs, s->d_reward, s->d_done, comps ? s->d_comps : nullptr, nullptr, s->stream);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(obs, s->d_obs, n * s->obs_dim * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipMemcpyAsync(reward, s->d_reward, n * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipMemcpyAsync(done, s->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    if (comps) HIP_TRY(hipMemcpyAsync(comps, s->d_comps, n * QG_NREWARD * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+static int copy_out(qg_sim *s, const float *field_major, float *host, int w) {
+    if (!host) return QG_OK;
+    int total = s->n * w, threads = 256;
+    hipLaunchKernelGGL(qg_transpose_out, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, field_major, s->d_stage, s->n, w);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    HIP_TRY(hipMemcpyAsync(host, s->d_stage, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+static int copy_in(qg_sim *s, const float *host, float *field_major, int w) {
+    if (!host) return QG_OK;
+    int total = s->n * w, threads = 256;
+    HIP_TRY(hipMemcpyAsync(s->d_stage, host, (size_t)total * sizeof(float), hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
+    hipLaunchKernelGGL(qg_transpose_in, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, s->d_stage, field_major, s->n, w);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+extern "C" int qg_get_state(qg_sim *s, float *qpos, float *qvel, float *act, float *ctrl, int32_t *nstep) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps may be in flight on a caller's stream
+    int rc;
+    if ((rc = copy_out(s, s->st.qpos, qpos, QG_NQ)) != QG_OK) return rc;
+    if ((rc = copy_out(s, s->st.qvel, qvel, QG_NV)) != QG_OK) return rc;
+    if ((rc = copy_out(s, s->st.act, act, QG_NU)) != QG_OK) return rc;
+    if ((rc = copy_out(s, s->st.ctrl, ctrl, QG_NU)) != QG_OK) return rc;
+    if (nstep) HIP_TRY(hipMemcpy(nstep, s->st.nstep, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    return QG_OK;
+}
+
+extern "C" int qg_set_state(qg_sim *s, const float *qpos, const float *qvel, const float *act, const float *ctrl, const int32_t *nstep) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    int rc;
+    if ((rc = copy_in(s, qpos, s->st.qpos, QG_NQ)) != QG_OK) return rc;
+    if ((rc = copy_in(s, qvel, s->st.qvel, QG_NV)) != QG_OK) return rc;
+    if ((rc = copy_in(s, act, s->st.act, QG_NU)) != QG_OK) return rc;
+    if ((rc = copy_in(s, ctrl, s->st.ctrl, QG_NU)) != QG_OK) return rc;
+    if (nstep) HIP_TRY(hipMemcpy(s->st.nstep, nstep, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice), QG_ERR_DEVICE);
+    return QG_OK;
+}
+
+extern "C" int qg_time_step_kernel(qg_sim *s, const float *d_actions, float *d_packed, int32_t iters, float *ms_per_launch) {
+    if (!s || !d_actions || !d_packed || iters < 1 || !ms_per_launch) return fail(QG_ERR_ARG, "qg_time_step_kernel: bad argument");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    int keep = s->track_ctrl;
+    s->track_ctrl = 0;
+    HIP_TRY(hipEventRecord(s->ev0, s->stream), QG_ERR_DEVICE);
+    for (int i = 0; i < iters; i++) {
+        int rc = launch_step(s, d_actions, nullptr, nullptr, nullptr, nullptr, d_packed, s->stream);
+        if (rc != QG_OK) { s->track_ctrl = keep; return rc; }
+    }
+    HIP_TRY(hipEventRecord(s->ev1, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipEventSynchronize(s->ev1), QG_ERR_LAUNCH);
+    s->track_ctrl = keep;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1), QG_ERR_DEVICE);
+    *ms_per_launch = ms / (float)iters;
+    return QG_OK;
+}
+
+/* selects whether data.ctrl is written back each step (needed by QuadrupedEnv's `data.ctrl` view; off for raw throughput) */
+extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    s->track_ctrl = on ? 1 : 0;
+    return QG_OK;
+}

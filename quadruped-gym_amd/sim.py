@@ -1,0 +1,146 @@
+"""``BatchedSim`` -- thin Python handle over the C ABI (``include/quadgym.h``).
+
+PyTorch is used only as plumbing: it owns the device buffers that are handed to
+``qg_step_device*`` as raw pointers and provides the HIP stream.  The physics
+runs in ``libquadgym.so`` (hand-written gfx950 kernels); there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import NQ, NV, NU, NREWARD, QgModel, QgTask, check
+
+
+class BatchedSim:
+    """n independent quadrupeds on one GPU.
+
+    Replaces, for a whole batch, what ``QuadrupedEnv.__init__/reset/step`` do for
+    one robot through ``mujoco`` (``src/envs/quadruped.py:59-60,115-139,153-182``).
+    """
+
+    def __init__(self, n_envs: int, device: int = 0, model: QgModel | None = None, task: QgTask | None = None,
+                 env_index_base: int = 0):
+        self._lib = _abi.load_library()
+        self.model = model if model is not None else _abi.default_model()
+        self.task = task if task is not None else _abi.default_task()
+        self.n = int(n_envs)
+        self.device = int(device)
+        self.env_index_base = int(env_index_base)
+        h = C.c_void_p()
+        check(self._lib.qg_create(self.n, self.device, C.byref(self.model), C.byref(self.task), self.env_index_base,
+                                  C.byref(h)), "qg_create")
+        self._h = h
+        self.obs_dim = self._lib.qg_obs_dim(self._h)
+        self.limit_substeps = int(self._lib.qg_time_limit_substeps(self.model.timestep, self.task.max_time))
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.qg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reset / step through host (NumPy) buffers ------------------------------------------------
+    def reset(self, mask=None, seed: int = 0, flags: int = 0):
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert mask.shape == (self.n,)
+            mp = mask.ctypes.data
+        check(self._lib.qg_reset(self._h, mp, int(seed), int(flags)), "qg_reset")
+
+    def step(self, actions, want_components: bool = False):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.n, NU):
+            raise ValueError(f"actions must have shape ({self.n}, {NU}), got {a.shape}")
+        obs = np.empty((self.n, self.obs_dim), np.float32)
+        rew = np.empty(self.n, np.float32)
+        done = np.empty(self.n, np.uint8)
+        comps = np.empty((self.n, NREWARD), np.float32) if want_components else None
+        check(self._lib.qg_step(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data,
+                                comps.ctypes.data if want_components else None), "qg_step")
+        return obs, rew, done.astype(bool), comps
+
+    # -- zero-copy forms on torch (ROCm) tensors ---------------------------------------------------
+    def _stream_ptr(self, stream):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device)
+        return C.c_void_p(stream.cuda_stream)
+
+    def _check_tensor(self, t, shape, dtype):
+        if not t.is_cuda or t.device.index != self.device:
+            raise ValueError(f"tensor must live on cuda:{self.device}")
+        if tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous():
+            raise ValueError(f"expected contiguous {dtype} tensor of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)}")
+
+    def step_device(self, actions, obs, reward, done, comps=None, stream=None):
+        import torch
+        self._check_tensor(actions, (self.n, NU), torch.float32)
+        self._check_tensor(obs, (self.n, self.obs_dim), torch.float32)
+        self._check_tensor(reward, (self.n,), torch.float32)
+        self._check_tensor(done, (self.n,), torch.uint8)
+        if comps is not None:
+            self._check_tensor(comps, (self.n, NREWARD), torch.float32)
+        check(self._lib.qg_step_device(self._h, actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                                       comps.data_ptr() if comps is not None else None, self._stream_ptr(stream)),
+              "qg_step_device")
+
+    def step_device_packed(self, actions, packed, stream=None):
+        """obs, reward and done (0/1) in one ``[n, obs_dim + 2]`` f32 buffer: the unit of the per-step RCCL gather."""
+        import torch
+        self._check_tensor(actions, (self.n, NU), torch.float32)
+        self._check_tensor(packed, (self.n, self.obs_dim + 2), torch.float32)
+        check(self._lib.qg_step_device_packed(self._h, actions.data_ptr(), packed.data_ptr(), self._stream_ptr(stream)),
+              "qg_step_device_packed")
+
+    def time_step_kernel(self, actions, packed, iters: int) -> float:
+        """Mean milliseconds per launch of the step kernel over ``iters`` back-to-back launches,
+        measured with HIP events on the stream the kernel is launched on."""
+        import torch
+        self._check_tensor(actions, (self.n, NU), torch.float32)
+        self._check_tensor(packed, (self.n, self.obs_dim + 2), torch.float32)
+        ms = C.c_float()
+        check(self._lib.qg_time_step_kernel(self._h, actions.data_ptr(), packed.data_ptr(), int(iters), C.byref(ms)),
+              "qg_time_step_kernel")
+        return float(ms.value)
+
+    def set_track_ctrl(self, on: bool):
+        check(self._lib.qg_set_track_ctrl(self._h, 1 if on else 0), "qg_set_track_ctrl")
+
+    # -- state snapshot / restore ---------------------------------------------------------------
+    def get_state(self):
+        qpos = np.empty((self.n, NQ), np.float32)
+        qvel = np.empty((self.n, NV), np.float32)
+        act = np.empty((self.n, NU), np.float32)
+        ctrl = np.empty((self.n, NU), np.float32)
+        nstep = np.empty(self.n, np.int32)
+        check(self._lib.qg_get_state(self._h, qpos.ctypes.data, qvel.ctypes.data, act.ctypes.data, ctrl.ctypes.data,
+                                     nstep.ctypes.data), "qg_get_state")
+        return qpos, qvel, act, ctrl, nstep
+
+    def set_state(self, qpos=None, qvel=None, act=None, ctrl=None, nstep=None):
+        def f32(x, w):
+            if x is None:
+                return None, None
+            a = np.ascontiguousarray(x, dtype=np.float32)
+            if a.shape != (self.n, w):
+                raise ValueError(f"expected shape ({self.n}, {w}), got {a.shape}")
+            return a, a.ctypes.data
+        qp, qpp = f32(qpos, NQ)
+        qv, qvp = f32(qvel, NV)
+        ac, acp = f32(act, NU)
+        ct, ctp = f32(ctrl, NU)
+        ns, nsp = None, None
+        if nstep is not None:
+            ns = np.ascontiguousarray(nstep, dtype=np.int32)
+            nsp = ns.ctypes.data
+        check(self._lib.qg_set_state(self._h, qpp, qvp, acp, ctp, nsp), "qg_set_state")

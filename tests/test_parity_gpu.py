@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+vectors.  Floating point: the kernels compute in f32, the oracle in f64; tolerances are stated
+per quantity below and hold for ONE env-step from identical f32 states (longer rollouts diverge
+chaotically in any precision and are compared through invariants instead)."""
+import os
+
+import numpy as np
+import pytest
+
+from quadruped_gym_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_vectors.npz")
+
+# ---- stated tolerances: |gpu - oracle| <= atol + rtol * |oracle| after one env-step ----------
+TOL = {
+    # frame_skip 4 (case A)                     frame_skip 20 (case B): error grows with the substeps
+    "A": dict(qpos=(2e-5, 1e-5), qvel=(5e-3, 2e-3), act=(1e-6, 1e-6), obs=(5e-3, 2e-3), accel=(0.25, 5e-3), reward=(5e-3, 1e-3)),
+    "B": dict(qpos=(4e-4, 1e-4), qvel=(5e-2, 2e-2), act=(1e-6, 1e-6), obs=(5e-2, 2e-2), accel=(2.0, 5e-2), reward=(5e-2, 1e-2)),
+}
+
+
+def configure(task, case):
+    task.use_fall = 1
+    task.fall_height = 0.05
+    if case == "B":
+        task.frame_skip = 20
+        task.obs_mode = 1
+    return task
+
+
+def close(got, ref, tol, what):
+    atol, rtol = tol
+    err = np.abs(np.asarray(got, np.float64) - ref)
+    bound = atol + rtol * np.abs(ref)
+    worst = np.unravel_index(np.argmax(err - bound), err.shape)
+    assert (err <= bound).all(), f"{what}: max excess at {worst}: got {np.asarray(got)[worst]}, ref {ref[worst]}, err {err[worst]:.3e}"
+    return float(err.max())
+
+
+def accel_slice(case):
+    return slice(12, 15)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+@pytest.mark.parametrize("case", ["A", "B"])
+def test_step_matches_golden_vectors(gold, case):
+    from quadruped_gym_amd.sim import BatchedSim
+    task = configure(_abi.default_task(), case)
+    n = len(gold["qpos"])
+    sim = BatchedSim(n, task=task)
+    sim.set_state(gold["qpos"], gold["qvel"], gold["act"], None, gold["nstep"])
+    obs, rew, done, comps = sim.step(gold["actions"], want_components=True)
+    q1, v1, a1, c1, n1 = sim.get_state()
+    t = TOL[case]
+    g = lambda k: gold[case + "_" + k]
+    close(q1, g("qpos1"), t["qpos"], "qpos")
+    close(v1, g("qvel1"), t["qvel"], "qvel")
+    close(a1, g("act1"), t["act"], "act")
+    assert np.array_equal(n1, g("nstep1"))
+    assert np.array_equal(c1, g("ctrl1").astype(np.float32))       # data.ctrl = clip(action, -1, 1): exact
+    sl = accel_slice(case)
+    mask = np.ones(obs.shape[1], bool)
+    mask[sl] = False
+    close(obs[:, mask], g("obs")[:, mask], t["obs"], "obs")
+    close(obs[:, sl], g("obs")[:, sl], t["accel"], "accelerometer")
+    close(rew, g("reward"), t["reward"], "reward")
+    close(comps, g("comps"), t["reward"], "reward components")
+    # terminations are threshold tests on f32 vs f64 states: identical except within rounding of the threshold
+    z1 = g("qpos1")[:, 2]
+    sure = np.abs(z1 - 0.05) > 1e-4
+    assert np.array_equal(done[sure], g("done")[sure])
+    sim.close()
+
+
+def test_step_matches_oracle_on_fresh_states(oracle):
+    """Seeded states the fixture does not hold, through the device-pointer entry points."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_golden import sample_states
+    model, task = oracle.default_model(), configure(oracle.default_task(), "A")
+    n = 200                                               # ragged: 3 full waves + 8 lanes
+    qpos, qvel, act, nstep = sample_states(model, task, n, seed=99)
+    rng = np.random.default_rng(5)
+    actions = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+    b = oracle.Batch(model, task, n)
+    b.set_state(qpos.astype(np.float64), qvel.astype(np.float64), act.astype(np.float64), None, nstep)
+    obs_o, rew_o, done_o, comps_o = b.step(actions.astype(np.float64))
+    q_o, v_o, a_o, _, n_o = b.get_state()
+
+    sim = BatchedSim(n, task=configure(_abi.default_task(), "A"))
+    sim.set_state(qpos, qvel, act, None, nstep)
+    dev = torch.device("cuda:0")
+    a_d = torch.from_numpy(actions).to(dev)
+    packed = torch.full((n, 35), float("nan"), device=dev)
+    sim.step_device_packed(a_d, packed)
+    torch.cuda.synchronize()
+    p = packed.cpu().numpy()
+    assert np.isfinite(p).all()
+    t = TOL["A"]
+    mask = np.ones(33, bool)
+    mask[12:15] = False
+    close(p[:, :33][:, mask], obs_o[:, mask], t["obs"], "obs")
+    close(p[:, 12:15], obs_o[:, 12:15], t["accel"], "accelerometer")
+    close(p[:, 33], rew_o, t["reward"], "reward")
+    q1, v1, a1, _, n1 = sim.get_state()
+    close(q1, q_o, t["qpos"], "qpos")
+    close(v1, v_o, t["qvel"], "qvel")
+    close(a1, a_o, t["act"], "act")
+    assert np.array_equal(n1, n_o)
+    sure = np.abs(q_o[:, 2] - 0.05) > 1e-4
+    assert np.array_equal(p[sure, 34] > 0.5, done_o[sure])
+    sim.close()
+
+
+def test_reset_contract_and_first_observation():
+    """quadruped.py:115-139: qpos0, zero velocity/activation, ctrl = [0, 0, -0.5]*4, time 0."""
+    from quadruped_gym_amd.sim import BatchedSim
+    sim = BatchedSim(130)
+    m = sim.model
+    qpos, qvel, act, ctrl, nstep = sim.get_state()
+    assert np.allclose(qpos, np.array(m.qpos0[:], np.float32)[None])
+    assert not qvel.any() and not act.any() and not nstep.any()
+    assert np.array_equal(ctrl, np.tile(np.array([0, 0, -0.5] * 4, np.float32), (130, 1)))
+    # masked reset leaves the other envs alone
+    a = np.random.default_rng(0).uniform(-1, 1, (130, 12)).astype(np.float32)
+    sim.step(a)
+    before = sim.get_state()
+    mask = np.zeros(130, np.uint8)
+    mask[[0, 64, 129]] = 1
+    sim.reset(mask=mask)
+    after = sim.get_state()
+    assert np.allclose(after[0][mask == 1], np.array(m.qpos0[:], np.float32)[None])
+    assert np.array_equal(after[0][mask == 0], before[0][mask == 0])
+    assert np.array_equal(after[4], np.where(mask == 1, 0, 4))
+    sim.close()
+
+
+def test_random_yaw_reset_matches_oracle_stream(oracle):
+    from quadruped_gym_amd.sim import BatchedSim
+    sim = BatchedSim(100, env_index_base=1000)
+    sim.reset(seed=42, flags=_abi.RESET_RANDOM_YAW)
+    qpos = sim.get_state()[0]
+    a = np.array([2 * np.pi * oracle.uniform(42, 1000 + i, 0) for i in range(100)])
+    assert np.allclose(qpos[:, 3], np.cos(a / 2), atol=2e-7) and np.allclose(qpos[:, 6], np.sin(a / 2), atol=2e-7)
+    assert not qpos[:, 4:6].any()
+    sim.close()
+
+
+def test_time_limit_terminates_and_auto_reset():
+    """`time >= max_time` is reported as terminated on the exact substep the f64-accumulated clock
+    crosses it (quadruped.py:149-151); with auto_reset the env restarts inside the same launch."""
+    from quadruped_gym_amd.sim import BatchedSim
+    task = _abi.default_task()
+    task.max_time = 0.05           # 25 substeps -> 7th env-step at frame_skip 4 (28 >= 25... first >= is step 7)
+    task.auto_reset = 1
+    sim = BatchedSim(70, task=task)
+    lim = sim.limit_substeps
+    a = np.zeros((70, 12), np.float32)
+    k_done = None
+    for k in range(1, 12):
+        obs, rew, done, _ = sim.step(a)
+        if done.all():
+            k_done = k
+            break
+        assert not done.any()
+    assert k_done == -(-lim // 4)
+    qpos, qvel, act, ctrl, nstep = sim.get_state()
+    assert not nstep.any() and not qvel.any() and np.allclose(qpos, np.array(sim.model.qpos0[:], np.float32)[None])
+    assert np.abs(obs).sum() > 0                      # the terminal observation is returned, not the reset one
+    sim.close()
+
+
+def test_full_size_invariants():
+    """BASELINE config 2 size (4096 envs): properties that need no oracle."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    n = 4096
+    task = _abi.default_task()
+    sim = BatchedSim(n, task=task)
+    rng = np.random.default_rng(3)
+    dev = torch.device("cuda:0")
+    packed = torch.empty((n, 35), device=dev)
+    acts = [torch.from_numpy(rng.uniform(-1, 1, (n, 12)).astype(np.float32)).to(dev) for _ in range(8)]
+    for k in range(120):
+        sim.step_device_packed(acts[k % 8], packed)
+    torch.cuda.synchronize()
+    qpos, qvel, act, _, nstep = sim.get_state()
+    assert np.isfinite(qpos).all() and np.isfinite(qvel).all()
+    assert np.allclose(np.linalg.norm(qpos[:, 3:7], axis=1), 1.0, atol=1e-5)      # unit quaternions
+    assert (nstep == 480).all()
+    assert qpos[:, 2].min() > 0.0 and np.abs(qvel).max() < 100.0                     # nobody fell through the floor
+    assert (np.abs(act) <= np.array([0.5, 0.91, 1.0] * 4) + 1e-6).all()              # activations inside the ctrlrange
+    # identical envs in different lanes / waves produce identical bits; different actions differ
+    sim2 = BatchedSim(n, task=task)
+    same = torch.from_numpy(np.tile(rng.uniform(-1, 1, (1, 12)).astype(np.float32), (n, 1))).to(dev)
+    for k in range(30):
+        sim2.step_device_packed(same, packed)
+    torch.cuda.synchronize()
+    q2 = sim2.get_state()[0]
+    assert (q2 == q2[0:1]).all()
+    p = packed.cpu().numpy()
+    assert (p == p[0:1]).all()
+    sim.close(); sim2.close()
+
+
+def test_sharding_does_not_change_results():
+    """Two handles of 128 envs with env_index_base 0 / 128 reproduce one handle of 256 bit for bit
+    (per-env random streams are keyed by the global env index)."""
+    from quadruped_gym_amd.sim import BatchedSim
+    task = _abi.default_task()
+    task.auto_reset = 1
+    task.max_time = 0.04
+    task.reset_flags = _abi.RESET_RANDOM_YAW
+    rng = np.random.default_rng(11)
+    whole = BatchedSim(256, task=task)
+    parts = [BatchedSim(128, task=task, env_index_base=0), BatchedSim(128, task=task, env_index_base=128)]
+    for s in [whole] + parts:
+        s.reset(seed=9, flags=_abi.RESET_RANDOM_YAW)
+    for k in range(12):
+        a = rng.uniform(-1, 1, (256, 12)).astype(np.float32)
+        ow = whole.step(a)
+        op = [parts[0].step(a[:128]), parts[1].step(a[128:])]
+        assert np.array_equal(ow[0], np.concatenate([op[0][0], op[1][0]]))
+        assert np.array_equal(ow[2], np.concatenate([op[0][2], op[1][2]]))
+    sw = whole.get_state()
+    sp = [p.get_state() for p in parts]
+    assert np.array_equal(sw[0], np.concatenate([sp[0][0], sp[1][0]]))
+    for s in [whole] + parts:
+        s.close()
