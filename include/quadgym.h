@@ -80,12 +80,14 @@ typedef struct qg_model {
     double act_kp[QG_NU], act_kv[QG_NU], act_gear[QG_NU], act_timeconst[QG_NU];
     double act_ctrlrange[QG_NU][2], act_forcerange[QG_NU][2];
     double limit_stiffness, limit_damping; /* soft joint limits (N m/rad, N m s/rad) */
+    double limit_ramp;                     /* limit damping ramps in linearly over this penetration (rad) */
     int32_t ncp[QG_NBODY];                 /* must be 12 for FRAME, 8 for every link */
     double cp[QG_NBODY][QG_MAXCP][3];      /* contact sample points, body frame */
     double contact_stiffness;              /* N/m per sample point */
     double contact_damping;                /* N s/m per body in contact (implicit) */
     double contact_margin;                 /* contact starts at this height */
     double contact_friction;               /* Coulomb mu */
+    double contact_ramp;                   /* contact damping ramps in linearly over this summed penetration (m) */
     double qpos0[QG_NQ];                   /* what mj_resetData restores (quadruped.py:120) */
 } qg_model;
 

@@ -381,16 +381,20 @@ int qgo_substep(const qg_model *m, qgo_env *e, const double *ctrl, double *sens,
         int d = 6 + j;
         double q = e->qpos[7 + j], qd = e->qvel[d];
         double lo = m->jnt_range[j][0], hi = m->jnt_range[j][1];
-        double kl = m->limit_stiffness, bl = m->limit_damping;
+        double kl = m->limit_stiffness;
+        double pen = q < lo ? lo - q : (q > hi ? q - hi : 0.0);
+        /* the damper ramps in with the penetration so the torque is continuous at the limit */
+        double ramp = pen / m->limit_ramp;
+        double bl = m->limit_damping * (ramp < 1.0 ? ramp : 1.0);
         if (q < lo) {
-            double spring = kl * (lo - q);
+            double spring = kl * pen;
             double t = spring - bl * qd;
             double beff = bl;
             if (t < 0) { t = 0; beff = spring / qd; }     /* qd > 0 here: leaving the limit fast */
             flim[d] = t;
             A[d * NV + d] += h * beff;
         } else if (q > hi) {
-            double spring = kl * (q - hi);
+            double spring = kl * pen;
             double t = spring + bl * qd;
             double beff = bl;
             if (t < 0) { t = 0; beff = -spring / qd; }    /* qd < 0 */
@@ -401,13 +405,14 @@ int qgo_substep(const qg_model *m, qgo_env *e, const double *ctrl, double *sens,
 
     /* LCP-free soft ground contact (plane z = 0), one aggregated contact per body:
      *   W   = sum_i k * max(0, margin - z_i)          spring force
+ *   c   = contact_damping * min(1, sum_i pen_i / contact_ramp)   damper ramps in with depth
      *   P   = centre of pressure of the spring forces
      *   F_n = max(0, W - c * v_n(P))                  no adhesion
      *   F_t = -min(c, mu F_n / |v_t|) * v_t(P)        viscous, Coulomb-limited
      * The damper is linear in velocity with the secant coefficients (c_n, c_t), and
      * h * J^T diag(c_t, c_t, c_n) J is added to the implicit matrix. */
     for (int b = 0; b < NB; b++) {
-        double W = 0, s[3] = {0, 0, 0};
+        double W = 0, s[3] = {0, 0, 0}, pensum = 0;
         for (int i = 0; i < m->ncp[b]; i++) {
             double r[3];
             matvec3(k.R[b], m->cp[b][i], r);
@@ -415,6 +420,7 @@ int qgo_substep(const qg_model *m, qgo_env *e, const double *ctrl, double *sens,
             double pen = m->contact_margin - z;
             if (pen > 0) {
                 double w = m->contact_stiffness * pen;
+                pensum += pen;
                 W += w;
                 for (int t = 0; t < 3; t++) s[t] += w * r[t];
             }
@@ -436,7 +442,8 @@ int qgo_substep(const qg_model *m, qgo_env *e, const double *ctrl, double *sens,
         double vP[3] = {0, 0, 0};
         for (int d = 0; d < NV; d++)
             for (int t = 0; t < 3; t++) vP[t] += J[t][d] * e->qvel[d];
-        double c = m->contact_damping, mu = m->contact_friction;
+        double ramp = pensum / m->contact_ramp;
+        double c = m->contact_damping * (ramp < 1.0 ? ramp : 1.0), mu = m->contact_friction;
         double cn = c, Fn = W - c * vP[2];
         if (Fn < 0) { Fn = 0; cn = W / vP[2]; }
         double speed = sqrt(vP[0] * vP[0] + vP[1] * vP[1]);

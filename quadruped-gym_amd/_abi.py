@@ -40,12 +40,14 @@ class QgModel(C.Structure):
         ("act_forcerange", (C.c_double * 2) * NU),
         ("limit_stiffness", C.c_double),
         ("limit_damping", C.c_double),
+        ("limit_ramp", C.c_double),
         ("ncp", C.c_int32 * NBODY),
         ("cp", ((C.c_double * 3) * MAXCP) * NBODY),
         ("contact_stiffness", C.c_double),
         ("contact_damping", C.c_double),
         ("contact_margin", C.c_double),
         ("contact_friction", C.c_double),
+        ("contact_ramp", C.c_double),
         ("qpos0", C.c_double * NQ),
     ]
 

@@ -105,6 +105,7 @@ static void quat_to_rowmajor(const double q[4], float R[9]) {
 
 static int build_tables(const qg_model *m, const qg_task *t, KModel *km, KTask *kt) {
     if (!(m->timestep > 0)) return fail(QG_ERR_ARG, "model.timestep must be positive");
+    if (!(m->limit_ramp > 0) || !(m->contact_ramp > 0)) return fail(QG_ERR_ARG, "model.limit_ramp and model.contact_ramp must be positive");
     if (m->body_parent[0] != -1) return fail(QG_ERR_ARG, "body 0 must be the free-floating FRAME");
     if (m->ncp[0] != QGK_CP_FRAME) return fail(QG_ERR_ARG, "FRAME must carry %d contact points", QGK_CP_FRAME);
     for (int b = 1; b < QG_NBODY; b++) {
@@ -146,6 +147,8 @@ static int build_tables(const qg_model *m, const qg_task *t, KModel *km, KTask *
     km->contact_mu = (float)m->contact_friction;
     km->limit_k = (float)m->limit_stiffness;
     km->limit_b = (float)m->limit_damping;
+    km->limit_inv_ramp = (float)(1.0 / m->limit_ramp);
+    km->contact_inv_ramp = (float)(1.0 / m->contact_ramp);
     for (int i = 0; i < QG_NQ; i++) km->qpos0[i] = (float)m->qpos0[i];
     for (int j = 0; j < QGK_NLINK; j++) {
         KLink &L = km->link[j];

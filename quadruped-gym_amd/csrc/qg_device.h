@@ -31,8 +31,8 @@ struct KModel {
     float m0, h0[3], I0[6];
     float free_damping, free_armature;
     float cp0[QGK_CP_FRAME][3];
-    float contact_k, contact_c, contact_margin, contact_mu;
-    float limit_k, limit_b;
+    float contact_k, contact_c, contact_margin, contact_mu, contact_inv_ramp;
+    float limit_k, limit_b, limit_inv_ramp;
     float qpos0[19];
     KLink link[QGK_NLINK];
 };

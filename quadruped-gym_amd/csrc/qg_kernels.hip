@@ -153,13 +153,14 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
 // ground contact of one body: LCP-free penalty model, one aggregated contact per body
 //   W   = sum_i k * max(0, margin - z_i)      spring force of the sample points below the margin
 //   P   = centre of pressure of those spring forces
+//   c   = contact_c * min(1, sum_i pen_i / ramp)      the damper ramps in with depth (continuous force)
 //   F_n = max(0, W - c v_n(P));   F_t = -min(c, mu F_n / |v_t|) v_t(P)
 // The damper is linear in the velocity with secant coefficients (c_n, c_t); it enters the
 // system matrix as h * (c_t * point-mass(P) + (c_n - c_t) a a^T), a = [P x n; n].
 // ------------------------------------------------------------------------------------------
 template <int NCP>
-DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V3 n, SV v, float kc, float cc, float margin,
-                      float mu, float h, SV &f_ext, Sym6 &A) {
+DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V3 n, SV v, float kc, float cmax, float inv_ramp,
+                      float margin, float mu, float h, SV &f_ext, Sym6 &A) {
     V3 nl = rotT(E, n);                 // world up in the body's own axes
     float wsum = 0.f;
     V3 s = v3(0.f, 0.f, 0.f);
@@ -173,6 +174,7 @@ DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V
     }
     bool active = wsum > 0.f;
     float W = kc * wsum;
+    float cc = cmax * fminf(wsum * inv_ramp, 1.f);
     float inv = rcp(active ? wsum : 1.f);
     V3 P = p + rot(E, inv * s);         // centre of pressure, FRAME axes about the FRAME origin
     V3 vP = v.l + cross(v.a, P);
@@ -241,8 +243,8 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
     {
         Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
         SV fe;
-        body_contact<QGK_CP_FRAME>(M->cp0, E0, v3(0.f, 0.f, 0.f), B.pw.z, n, V0, M->contact_k, M->contact_c, M->contact_margin,
-                                   M->contact_mu, h, fe, Ic0);
+        body_contact<QGK_CP_FRAME>(M->cp0, E0, v3(0.f, 0.f, 0.f), B.pw.z, n, V0, M->contact_k, M->contact_c, M->contact_inv_ramp,
+                                   M->contact_margin, M->contact_mu, h, fe, Ic0);
         p0.a = p0.a - fe.a;
         p0.l = p0.l - fe.l;
     }
@@ -307,8 +309,8 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
             f[i].l = Ia.l + cross(v.a, Iv.l);
             Ag[i] = sym6_of(Bi);
             SV fe;
-            body_contact<QGK_CP_LINK>(L.cp, E, p, B.pw.z + dot(n, p), n, v, M->contact_k, M->contact_c, M->contact_margin,
-                                      M->contact_mu, h, fe, Ag[i]);
+            body_contact<QGK_CP_LINK>(L.cp, E, p, B.pw.z + dot(n, p), n, v, M->contact_k, M->contact_c, M->contact_inv_ramp,
+                                      M->contact_margin, M->contact_mu, h, fe, Ag[i]);
             f[i].a = f[i].a - fe.a;
             f[i].l = f[i].l - fe.l;
             Ep = E; pp = p; vp = v; ap = a;
@@ -345,17 +347,19 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
             float tau = L.gear * force - L.damping * qd[i];
             // soft joint limits
             float below = L.lo - q, above = q - L.hi;
+            float pen = fmaxf(fmaxf(below, above), 0.f);
+            float bl = M->limit_b * fminf(pen * M->limit_inv_ramp, 1.f);   // damper ramps in: continuous torque
             if (below > 0.f) {
                 float spring = M->limit_k * below;
-                float t = spring - M->limit_b * qd[i];
-                float be = M->limit_b;
+                float t = spring - bl * qd[i];
+                float be = bl;
                 if (t < 0.f) { t = 0.f; be = spring * rcp(qd[i]); }
                 tau += t;
                 dimp += be;
             } else if (above > 0.f) {
                 float spring = M->limit_k * above;
-                float t = spring + M->limit_b * qd[i];
-                float be = M->limit_b;
+                float t = spring + bl * qd[i];
+                float be = bl;
                 if (t < 0.f) { t = 0.f; be = -spring * rcp(qd[i]); }
                 tau -= t;
                 dimp += be;

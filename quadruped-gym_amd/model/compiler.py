@@ -447,10 +447,12 @@ def _derive_soft_constraints(model):
         damping=400.0,                                       # N s/m per body in contact, treated implicitly
         margin=max(b["margin"] for b in model["bodies"]),    # quadruped.xml:8 (floor margin 0)
         friction=max(model["floor_friction"], max(b["friction"] for b in model["bodies"])),
+        ramp=5.0e-4,                                         # m of summed penetration over which the damper ramps in
     )
     # joint limits: stiffness scaled by a typical joint-space inertia (armature + link)
     i_eff = 2.0e-3
-    model["limit"] = dict(stiffness=round(i_eff * kref * stiff, 2), damping=round(2.0 * i_eff / (_SOLIMP_D0 * _SOLREF_TIMECONST), 4))
+    model["limit"] = dict(stiffness=round(i_eff * kref * stiff, 2), damping=round(2.0 * i_eff / (_SOLIMP_D0 * _SOLREF_TIMECONST), 4),
+                          ramp=0.01)                         # rad over which the limit damper ramps in
 
 
 # --------------------------------------------------------------------------- #
@@ -519,7 +521,8 @@ def emit_header(model, path):
     w("  /* act_timeconst */ %s, \\" % _c_arr([a["timeconst"] for a in A]))
     w("  /* act_ctrlrange */ {%s}, \\" % ", ".join(_c_arr(a["ctrlrange"]) for a in A))
     w("  /* act_forcerange */ {%s}, \\" % ", ".join(_c_arr(a["forcerange"]) for a in A))
-    w("  /* limit_stiffness */ %.17g, /* limit_damping */ %.17g, \\" % (model["limit"]["stiffness"], model["limit"]["damping"]))
+    w("  /* limit_stiffness */ %.17g, /* limit_damping */ %.17g, /* limit_ramp */ %.17g, \\"
+      % (model["limit"]["stiffness"], model["limit"]["damping"], model["limit"]["ramp"]))
     w("  /* ncp */ {%s}, \\" % ", ".join(str(len(b["contact_points"])) for b in B))
     cps = []
     for b in B:
@@ -529,8 +532,8 @@ def emit_header(model, path):
         cps.append("{" + ", ".join(_c_arr(p) for p in pts) + "}")
     w("  /* cp */ {%s}, \\" % ", \\\n    ".join(cps))
     c = model["contact"]
-    w("  /* contact_stiffness */ %.17g, /* contact_damping */ %.17g, /* contact_margin */ %.17g, /* contact_friction */ %.17g, \\"
-      % (c["stiffness"], c["damping"], c["margin"], c["friction"]))
+    w("  /* contact_stiffness */ %.17g, /* contact_damping */ %.17g, /* contact_margin */ %.17g, /* contact_friction */ %.17g, /* contact_ramp */ %.17g, \\"
+      % (c["stiffness"], c["damping"], c["margin"], c["friction"], c["ramp"]))
     w("  /* qpos0 */ %s \\" % _c_arr(qpos0(model)))
     w("}")
     w("#endif")
