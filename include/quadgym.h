@@ -165,6 +165,11 @@ int qg_time_step_kernel(qg_sim *sim, const float *d_actions, float *d_packed, in
  * while this is on (default on; bulk-throughput callers switch it off). */
 int qg_set_track_ctrl(qg_sim *sim, int32_t on);
 
+/* 1 when the handle's model equals the compiled-in default (include/qg_model_data.h) and the
+ * kernel variant with those constants baked into the instruction stream runs; 0 for any other
+ * numbers (generic variant, tables read from device memory). */
+int qg_uses_baked_model(const qg_sim *sim);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,7 @@ def load_library():
     lib.qg_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qg_time_step_kernel.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
     lib.qg_set_track_ctrl.argtypes = [vp, C.c_int32]
+    lib.qg_uses_baked_model.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
@@ -127,7 +128,7 @@ def load_library():
 EXPORTS = (
     "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
-    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl",
+    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model",
 )
 
 

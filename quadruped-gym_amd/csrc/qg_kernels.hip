@@ -29,8 +29,23 @@
 #include <stdint.h>
 
 #include "qg_device.h"
+#include "qg_model_baked.h"
 
 #define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------
+// model tables.  Two kernel variants: BAKED reads the default robot's constants from a `const`
+// device table with compile-time indices, so they become instruction literals (zeros and ones
+// fold away, nothing is loaded); the generic variant reads the same struct from a device buffer
+// through scalar loads and serves any other numbers.  The legs of the reference robot are
+// identical up to the mounting transform of the fema (quadruped.xml:71,89,107,125), so the baked
+// variant uses leg 0's link constants for every leg and only the mount (pos, Q) is read per leg.
+// ------------------------------------------------------------------------------------------
+static __device__ const KModel QG_BAKED_MODEL = {QG_BAKED_FLOATS};
+template <bool BAKED> DEV const KModel &table(const KModel *__restrict__ M) {
+    if constexpr (BAKED) return QG_BAKED_MODEL; else return *M;
+}
+template <bool BAKED> DEV const KLink &link_of(const KModel &C, int k, int i) { return C.link[BAKED ? i : 3 * k + i]; }
 
 // ------------------------------------------------------------------------------------------
 // small fixed-size algebra
@@ -209,7 +224,10 @@ struct BaseState { V3 pw; float qw, qx, qy, qz; V3 vw; V3 wb; };
 struct SensorOut { float accel[3]; V3 pw, vw, wb, vb, xaxis, zaxis; float jpos[12]; };
 
 // one physics substep for the env of this lane (mj_step of quadruped.py:165)
-DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane, BaseState &B, bool want_sensors, SensorOut &so) {
+template <bool BAKED>
+DEV void substep(const KModel *__restrict__ Mp, float *__restrict__ lds, int lane, BaseState &B, bool want_sensors, SensorOut &so) {
+    const KModel &C = table<BAKED>(Mp);
+    const KModel *M = &C;
     const float h = M->h;
     // ---- A. base prelude -----------------------------------------------------------------
     float qn = rcp(__builtin_amdgcn_sqrtf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz));
@@ -269,16 +287,17 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
         float qd[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const KLink &L = M->link[3 * k + i];
+            const KLink &L = link_of<BAKED>(C, k, i);
+            const KLink &Lm = (i == 0) ? C.link[3 * k] : L;   // the fema's mounting transform differs per leg
             const int j = 3 * k + i;
             float th = lds[LQ(j) * 64 + lane] - L.ref;      // rotation applied = qpos - ref
             qd[i] = lds[LQD(j) * 64 + lane];
             float sn, cs;
             sincos_f(th, sn, cs);
-            V3 p = pp + rot(Ep, ld3(L.pos));
-            V3 tx = fma3(L.Q[0], Ep.ex, fma3(L.Q[3], Ep.ey, L.Q[6] * Ep.ez));
-            V3 ty = fma3(L.Q[1], Ep.ex, fma3(L.Q[4], Ep.ey, L.Q[7] * Ep.ez));
-            V3 tz = fma3(L.Q[2], Ep.ex, fma3(L.Q[5], Ep.ey, L.Q[8] * Ep.ez));
+            V3 p = pp + rot(Ep, ld3(Lm.pos));
+            V3 tx = fma3(Lm.Q[0], Ep.ex, fma3(Lm.Q[3], Ep.ey, Lm.Q[6] * Ep.ez));
+            V3 ty = fma3(Lm.Q[1], Ep.ex, fma3(Lm.Q[4], Ep.ey, Lm.Q[7] * Ep.ez));
+            V3 tz = fma3(Lm.Q[2], Ep.ex, fma3(Lm.Q[5], Ep.ey, Lm.Q[8] * Ep.ez));
             Fr E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
             S[i].a = E.ez;
             S[i].l = cross(p, E.ez);
@@ -335,7 +354,7 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
         float bj[3], Hd[3] = {H00, H11, H22}, tb[3] = {t0, t1, t2};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const KLink &L = M->link[3 * k + i];
+            const KLink &L = link_of<BAKED>(C, k, i);
             const int j = 3 * k + i;
             float q = lds[LQ(j) * 64 + lane];
             float act = lds[LACT(j) * 64 + lane];
@@ -485,7 +504,7 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const KLink &L = M->link[3 * k + i];
+            const KLink &L = link_of<BAKED>(C, k, i);
             const int j = 3 * k + i;
             float acc = lds[LY(k, 18 + i) * 64 + lane];
 #pragma unroll
@@ -524,7 +543,9 @@ DEV void substep(const KModel *__restrict__ M, float *__restrict__ lds, int lane
 // env-step kernel: one launch = frame_skip substeps + sensor pack + rewards + terminations
 // (+ auto-reset) for every env.  grid = ceil(n / 64) workgroups of one wave.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restrict__ M, const KTask *__restrict__ T, KStepArgs P) {
+template <bool BAKED>
+__global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P) {
+    const KModel *M = &table<BAKED>(Mp);
     __shared__ float lds[QG_LDS_SLOTS * 64];
     __shared__ float tile[QG_OBS_TILE_FLOATS];
     const int lane = threadIdx.x;
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
             float a = fminf(fmaxf(av[j], -1.f), 1.f);
             aclip[j] = a;
             ssq = fmaf(a, a, ssq);
-            lds[LU(j) * 64 + lane] = fminf(fmaxf(a, M->link[j].ctrl_lo), M->link[j].ctrl_hi);
+            lds[LU(j) * 64 + lane] = fminf(fmaxf(a, M->link[BAKED ? j % 3 : j].ctrl_lo), M->link[BAKED ? j % 3 : j].ctrl_hi);
             lds[LQ(j) * 64 + lane] = P.st.qpos[(7 + j) * n + env];
             lds[LQD(j) * 64 + lane] = P.st.qvel[(6 + j) * n + env];
             lds[LACT(j) * 64 + lane] = P.st.act[j * n + env];
@@ -564,14 +585,14 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep(M, lds, lane, B, lag && (s == fs - 1), so);
+    for (int s = 0; s < fs; ++s) substep<BAKED>(Mp, lds, lane, B, lag && (s == fs - 1), so);
     nstep += fs;
     if (!lag) {   // un-lagged sensors: one extra forward pass on a scratch copy of the state
         BaseState B2 = B;
         float keep[36];
 #pragma unroll
         for (int j = 0; j < 36; ++j) keep[j] = lds[j * 64 + lane];
-        substep(M, lds, lane, B2, true, so);
+        substep<BAKED>(Mp, lds, lane, B2, true, so);
 #pragma unroll
         for (int j = 0; j < 36; ++j) lds[j * 64 + lane] = keep[j];
     }

@@ -327,6 +327,9 @@ def compile_mjcf(scene_path, mesh_inertia="convex"):
         for m, com, I in parts:
             d = com - ipos
             inertia += I + m * (d @ d * np.eye(3) - np.outer(d, d))
+        # symmetric bodies: remove round-off dust (far below the 1e-6 resolution of the OBJ vertices) so exact zeros stay zeros
+        ipos = np.where(np.abs(ipos) < 1e-9, 0.0, ipos)
+        inertia = np.where(np.abs(inertia) < 1e-6 * np.abs(np.diag(inertia)).max(), 0.0, inertia)
         # contact sample points: hull vertices of all the body's geoms, in the body frame
         cloud = []
         for g in b["geoms"]:

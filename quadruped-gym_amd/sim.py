@@ -34,6 +34,7 @@ class BatchedSim:
                                   C.byref(h)), "qg_create")
         self._h = h
         self.obs_dim = self._lib.qg_obs_dim(self._h)
+        self.baked = bool(self._lib.qg_uses_baked_model(self._h))
         self.limit_substeps = int(self._lib.qg_time_limit_substeps(self.model.timestep, self.task.max_time))
 
     # -- lifetime ---------------------------------------------------------------------------

@@ -120,6 +120,49 @@ def test_step_matches_oracle_on_fresh_states(oracle):
     sim.close()
 
 
+def test_generic_variant_matches_oracle_on_a_modified_robot(oracle):
+    """Any model other than the compiled-in default runs the generic kernel variant (tables read from
+    device memory instead of literals).  Heavier feet, a different servo gain and a shifted hip mount
+    must track the oracle given the same modified model."""
+    from quadruped_gym_amd.sim import BatchedSim
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_golden import sample_states
+
+    def tweak(m):
+        for k in range(4):
+            m.body_mass[3 + 3 * k] *= 1.3
+            m.act_kp[1 + 3 * k] = 80.0
+        m.body_pos[4][0] += 0.004           # leg 2's hip mount: legs no longer identical
+        m.contact_friction = 0.7
+        return m
+    model, task = tweak(oracle.default_model()), configure(oracle.default_task(), "A")
+    n = 96
+    qpos, qvel, act, nstep = sample_states(model, task, n, seed=123)
+    actions = np.random.default_rng(6).uniform(-1, 1, (n, 12)).astype(np.float32)
+    b = oracle.Batch(model, task, n)
+    b.set_state(qpos.astype(np.float64), qvel.astype(np.float64), act.astype(np.float64), None, nstep)
+    obs_o, rew_o, done_o, _ = b.step(actions.astype(np.float64))
+    q_o, v_o, a_o, _, _ = b.get_state()
+    sim = BatchedSim(n, model=tweak(_abi.default_model()), task=configure(_abi.default_task(), "A"))
+    assert not sim.baked
+    ref = BatchedSim(4)
+    assert ref.baked                        # the default robot takes the literal-constant variant
+    ref.close()
+    sim.set_state(qpos, qvel, act, None, nstep)
+    obs, rew, done, _ = sim.step(actions)
+    q1, v1, a1, _, _ = sim.get_state()
+    t = TOL["A"]
+    close(q1, q_o, t["qpos"], "qpos")
+    close(v1, v_o, t["qvel"], "qvel")
+    close(a1, a_o, t["act"], "act")
+    mask = np.ones(33, bool)
+    mask[12:15] = False
+    close(obs[:, mask], obs_o[:, mask], t["obs"], "obs")
+    close(rew, rew_o, t["reward"], "reward")
+    sim.close()
+
+
 def test_reset_contract_and_first_observation():
     """quadruped.py:115-139: qpos0, zero velocity/activation, ctrl = [0, 0, -0.5]*4, time 0."""
     from quadruped_gym_amd.sim import BatchedSim
