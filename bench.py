@@ -152,30 +152,27 @@ def main():
     gen.manual_seed(1234 + rank)                         # Philox, U(-1, 1), a pool cycled through the run
     pool = [torch.rand((n, 12), generator=gen, device=dev) * 2 - 1 for _ in range(16)]
     packed = [torch.empty((n, row), device=dev) for _ in range(2)]
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = [[torch.empty((n, row), device=dev) for _ in range(world)] for _ in range(2)]
     compute = torch.cuda.current_stream(dev)
-    comm = torch.cuda.Stream(dev) if world > 1 else None
-    step_done = [torch.cuda.Event() for _ in range(2)]
-    gather_done = [torch.cuda.Event() for _ in range(2)]
+    gatherer = None
+    if world > 1:
+        from quadruped_gym_amd.dist import PackedGatherer
+        gatherer = PackedGatherer(n, row, dev, dst=0)
 
     def run(k0, count):
         for k in range(k0, k0 + count):
             b = k & 1
-            if world > 1 and k >= 2:
-                compute.wait_event(gather_done[b])       # the gather that read packed[b] two steps ago
+            if gatherer is not None:
+                gatherer.wait_buffer_free(compute)       # the gather that read packed[b] two steps ago
             sim.step_device_packed(pool[k & 15], packed[b], stream=compute)
-            if world > 1:
-                step_done[b].record(compute)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(step_done[b])
-                    dist.gather(packed[b], gathered[b] if rank == 0 else None, dst=0)
-                    gather_done[b].record(comm)
-                if args.sync_gather:
-                    compute.wait_event(gather_done[b])
+            if gatherer is not None:
+                gatherer.submit(packed[b])               # RCCL gather on the communication stream
+                if len(gatherer.pending) > 1 or args.sync_gather:
+                    gatherer.collect()
 
     def fence():
+        if gatherer is not None:
+            while gatherer.pending:
+                gatherer.collect()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
