@@ -54,6 +54,11 @@ extern "C" {
 #define QG_OBS_FULL 0    /* the 33-value sensordata of quadruped.py:141-143 */
 #define QG_OBS_IMU 1     /* jointpos 12 + accel 3 + gyro 3 + velocimeter 3 = 21 (BASELINE config 5) */
 
+/* work mappings of the step kernel (qg_set_mapping) */
+#define QG_MAP_AUTO 0    /* QUAD below ~98k envs per GPU when the model is the compiled-in robot, else LANE */
+#define QG_MAP_LANE 1    /* one environment per wavefront lane (64 envs per wave), any model numbers */
+#define QG_MAP_QUAD 2    /* one leg per lane, four lanes per environment (16 envs per wave), compiled-in robot only */
+
 /* qg_reset flags */
 #define QG_RESET_RANDOM_YAW 1u   /* walking_quad.py:68-75: qpos[3:7] = [cos a/2, 0, 0, sin a/2], a ~ U(0, 2 pi) */
 
@@ -169,6 +174,11 @@ int qg_set_track_ctrl(qg_sim *sim, int32_t on);
  * kernel variant with those constants baked into the instruction stream runs; 0 for any other
  * numbers (generic variant, tables read from device memory). */
 int qg_uses_baked_model(const qg_sim *sim);
+
+/* Choose how environments map onto wavefront lanes (QG_MAP_*); results agree to rounding.
+ * qg_get_mapping returns the mapping the next step will actually use (LANE or QUAD). */
+int qg_set_mapping(qg_sim *sim, int32_t mapping);
+int qg_get_mapping(const qg_sim *sim);
 
 #ifdef __cplusplus
 }

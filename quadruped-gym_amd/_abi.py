@@ -12,6 +12,7 @@ import os
 NBODY, NJNT, NQ, NV, NU, NSENSOR, MAXCP, NREWARD = 13, 12, 19, 18, 12, 33, 12, 3
 OBS_FULL, OBS_IMU = 0, 1
 RESET_RANDOM_YAW = 1
+MAP_AUTO, MAP_LANE, MAP_QUAD = 0, 1, 2
 OBS_DIM = {OBS_FULL: 33, OBS_IMU: 21}
 
 
@@ -116,6 +117,8 @@ def load_library():
     lib.qg_time_step_kernel.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
     lib.qg_set_track_ctrl.argtypes = [vp, C.c_int32]
     lib.qg_uses_baked_model.argtypes = [vp]
+    lib.qg_set_mapping.argtypes = [vp, C.c_int32]
+    lib.qg_get_mapping.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
@@ -128,7 +131,7 @@ def load_library():
 EXPORTS = (
     "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
-    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model",
+    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
 )
 
 

@@ -172,21 +172,15 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
 //   F_n = max(0, W - c v_n(P));   F_t = -min(c, mu F_n / |v_t|) v_t(P)
 // The damper is linear in the velocity with secant coefficients (c_n, c_t); it enters the
 // system matrix as h * (c_t * point-mass(P) + (c_n - c_t) a a^T), a = [P x n; n].
+// Split in two so that the sample points of one body can be shared out over several lanes.
 // ------------------------------------------------------------------------------------------
-template <int NCP>
-DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V3 n, SV v, float kc, float cmax, float inv_ramp,
-                      float margin, float mu, float h, SV &f_ext, Sym6 &A) {
-    V3 nl = rotT(E, n);                 // world up in the body's own axes
-    float wsum = 0.f;
-    V3 s = v3(0.f, 0.f, 0.f);
-    float zb = margin - z_origin;
-#pragma unroll
-    for (int i = 0; i < NCP; ++i) {
-        V3 r = ld3(cp[i]);
-        float pen = fmaxf(zb - dot(nl, r), 0.f);
-        wsum += pen;
-        s = fma3(pen, r, s);
-    }
+DEV void contact_point(V3 r, V3 nl, float zb, float &wsum, V3 &s) {
+    float pen = fmaxf(zb - dot(nl, r), 0.f);
+    wsum += pen;
+    s = fma3(pen, r, s);
+}
+DEV void contact_finish(float wsum, V3 s, const Fr &E, V3 p, V3 n, SV v, float kc, float cmax, float inv_ramp, float mu, float h,
+                        SV &f_ext, Sym6 &A) {
     bool active = wsum > 0.f;
     float W = kc * wsum;
     float cc = cmax * fminf(wsum * inv_ramp, 1.f);
@@ -207,6 +201,294 @@ DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V
     f_ext.l = F;
     add_contact_damping(A, h * ct, h * (cn - ct), P, n);
 }
+template <int NCP>
+DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V3 n, SV v, float kc, float cmax, float inv_ramp,
+                      float margin, float mu, float h, SV &f_ext, Sym6 &A) {
+    V3 nl = rotT(E, n);                 // world up in the body's own axes
+    float wsum = 0.f;
+    V3 s = v3(0.f, 0.f, 0.f);
+    float zb = margin - z_origin;
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) contact_point(ld3(cp[i]), nl, zb, wsum, s);
+    contact_finish(wsum, s, E, p, n, v, kc, cmax, inv_ramp, mu, h, f_ext, A);
+}
+
+struct BaseState { V3 pw; float qw, qx, qy, qz; V3 vw; V3 wb; };
+
+// quantities of one substep that depend on the base state only
+struct BaseCtx {
+    float w, x, y, z;       // normalised quaternion
+    V3 cx, cy, cz;          // FRAME axes in world coordinates (columns of R)
+    V3 n, gb, vb;           // world up, gravity and base linear velocity in FRAME axes
+    SV V0, A0;              // spatial velocity of the FRAME; its spatial acceleration when the unknowns are zero
+};
+DEV BaseCtx base_prelude(const KModel &C, const BaseState &B) {
+    BaseCtx c;
+    float qn = rcp(__builtin_amdgcn_sqrtf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz));
+    float w = B.qw * qn, x = B.qx * qn, y = B.qy * qn, z = B.qz * qn;
+    c.w = w; c.x = x; c.y = y; c.z = z;
+    c.cx = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y));
+    c.cy = v3(2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x));
+    c.cz = v3(2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y));
+    c.n = v3(c.cx.z, c.cy.z, c.cz.z);
+    V3 gw = ld3(C.g);
+    c.gb = v3(dot(c.cx, gw), dot(c.cy, gw), dot(c.cz, gw));
+    c.vb = v3(dot(c.cx, B.vw), dot(c.cy, B.vw), dot(c.cz, B.vw));
+    c.V0.a = B.wb; c.V0.l = c.vb;
+    // unknowns are (d/dt w_b, classical acceleration of the FRAME origin); with both zero the
+    // spatial acceleration of the FRAME is [0; -w x v - g]
+    c.A0.a = v3(0.f, 0.f, 0.f);
+    c.A0.l = v3(0.f, 0.f, 0.f) - cross(B.wb, c.vb) - c.gb;
+    return c;
+}
+// FRAME body: bias force, rigid inertia, free-joint damping and armature on all six base DoFs
+// (quadruped.xml:9,62-63).  Contact of the FRAME is added by the caller.
+DEV void frame_body(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic0) {
+    Rigid I0 = {C.m0, ld3(C.h0), {C.I0[0], C.I0[1], C.I0[2], C.I0[3], C.I0[4], C.I0[5]}};
+    SV Iv0 = mul(I0, c.V0), Ia0 = mul(I0, c.A0);
+    p0.a = Ia0.a + cross(c.V0.a, Iv0.a) + cross(c.V0.l, Iv0.l);
+    p0.l = Ia0.l + cross(c.V0.a, Iv0.l);
+    Ic0 = sym6_of(I0);
+    float dg = C.free_armature + h * C.free_damping;
+    Ic0.AA.xx += dg; Ic0.AA.yy += dg; Ic0.AA.zz += dg;
+    Ic0.LL.xx += dg; Ic0.LL.yy += dg; Ic0.LL.zz += dg;
+    p0.a = fma3(C.free_damping, c.V0.a, p0.a);
+    p0.l = fma3(C.free_damping, c.V0.l, p0.l);
+}
+
+// ------------------------------------------------------------------------------------------
+// one leg: kinematics of fema / shin / foot, recursive Newton-Euler bias forces, ground contact,
+// composite (augmented) inertias = mass-matrix columns, servo / limit / damping terms.
+// `Ep0` is the frame the fema is mounted in: the identity (mount read from the table, leg k) in
+// the one-env-per-lane kernel; the quarter turn of leg k in the one-leg-per-lane kernel, where
+// the mount is then leg 0's (the legs are quarter-turn copies of one another).
+// Out: leg composite inertia Ic and force fc (to be added to the base rows), the base coupling
+// columns F[j], the leg block H = [[Hd0,H01,H02],[.,Hd1,H12],[.,.,Hd2]] and the right-hand side b.
+// ------------------------------------------------------------------------------------------
+template <bool BAKED, bool QUAD>
+DEV void leg_pass(const KModel &C, int k, Fr Ep, const float q[3], const float qd[3], const float act[3], const BaseCtx &bc, float zbase,
+                  float h, Sym6 &Ic, SV &fc, SV F[3], float Hd[3], float &H01, float &H02, float &H12, float bj[3]) {
+    V3 pp = v3(0.f, 0.f, 0.f);
+    SV vp = bc.V0, ap = bc.A0;
+    SV S[3], f[3];
+    Sym6 Ag[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const KLink &L = link_of<BAKED>(C, k, i);
+        const KLink &Lm = QUAD ? C.link[i] : ((i == 0) ? C.link[3 * k] : L);   // the fema's mounting transform differs per leg
+        float th = q[i] - L.ref;      // rotation applied = qpos - ref
+        float sn, cs;
+        sincos_f(th, sn, cs);
+        V3 p = pp + rot(Ep, ld3(Lm.pos));
+        V3 tx = fma3(Lm.Q[0], Ep.ex, fma3(Lm.Q[3], Ep.ey, Lm.Q[6] * Ep.ez));
+        V3 ty = fma3(Lm.Q[1], Ep.ex, fma3(Lm.Q[4], Ep.ey, Lm.Q[7] * Ep.ez));
+        V3 tz = fma3(Lm.Q[2], Ep.ex, fma3(Lm.Q[5], Ep.ey, Lm.Q[8] * Ep.ez));
+        Fr E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
+        S[i].a = E.ez;
+        S[i].l = cross(p, E.ez);
+        SV v = {fma3(qd[i], S[i].a, vp.a), fma3(qd[i], S[i].l, vp.l)};
+        // a = a_parent + (v x S) qd
+        SV a;
+        a.a = fma3(qd[i], cross(v.a, S[i].a), ap.a);
+        a.l = fma3(qd[i], cross(v.a, S[i].l) + cross(v.l, S[i].a), ap.l);
+        // rigid inertia of the link about the FRAME origin, FRAME axes
+        Rigid Bi;
+        Bi.m = L.mass;
+        V3 c = p + rot(E, ld3(L.ipos));
+        Bi.h = L.mass * c;
+        {
+            V3 ux = fma3(L.inertia[0], E.ex, fma3(L.inertia[3], E.ey, L.inertia[4] * E.ez));
+            V3 uy = fma3(L.inertia[3], E.ex, fma3(L.inertia[1], E.ey, L.inertia[5] * E.ez));
+            V3 uz = fma3(L.inertia[4], E.ex, fma3(L.inertia[5], E.ey, L.inertia[2] * E.ez));
+            float hc = dot(Bi.h, c);
+            Bi.I.xx = fmaf(ux.x, E.ex.x, fmaf(uy.x, E.ey.x, uz.x * E.ez.x)) + hc - Bi.h.x * c.x;
+            Bi.I.yy = fmaf(ux.y, E.ex.y, fmaf(uy.y, E.ey.y, uz.y * E.ez.y)) + hc - Bi.h.y * c.y;
+            Bi.I.zz = fmaf(ux.z, E.ex.z, fmaf(uy.z, E.ey.z, uz.z * E.ez.z)) + hc - Bi.h.z * c.z;
+            Bi.I.xy = fmaf(ux.x, E.ex.y, fmaf(uy.x, E.ey.y, uz.x * E.ez.y)) - Bi.h.x * c.y;
+            Bi.I.xz = fmaf(ux.x, E.ex.z, fmaf(uy.x, E.ey.z, uz.x * E.ez.z)) - Bi.h.x * c.z;
+            Bi.I.yz = fmaf(ux.y, E.ex.z, fmaf(uy.y, E.ey.z, uz.y * E.ez.z)) - Bi.h.y * c.z;
+        }
+        SV Iv = mul(Bi, v), Ia = mul(Bi, a);
+        f[i].a = Ia.a + cross(v.a, Iv.a) + cross(v.l, Iv.l);
+        f[i].l = Ia.l + cross(v.a, Iv.l);
+        Ag[i] = sym6_of(Bi);
+        SV fe;
+        body_contact<QGK_CP_LINK>(L.cp, E, p, zbase + dot(bc.n, p), bc.n, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
+                                  C.contact_margin, C.contact_mu, h, fe, Ag[i]);
+        f[i].a = f[i].a - fe.a;
+        f[i].l = f[i].l - fe.l;
+        Ep = E; pp = p; vp = v; ap = a;
+    }
+    // backward pass: composite inertias (mass-matrix columns) and bias torques
+    Ic = Ag[2];
+    fc = f[2];
+    F[2] = mul(Ic, S[2]);
+    float H22 = dot(S[2], F[2]), t2 = dot(S[2], fc);
+    H12 = dot(S[1], F[2]);
+    H02 = dot(S[0], F[2]);
+    add(Ic, Ag[1]);
+    fc = fc + f[1];
+    F[1] = mul(Ic, S[1]);
+    float H11 = dot(S[1], F[1]), t1 = dot(S[1], fc);
+    H01 = dot(S[0], F[1]);
+    add(Ic, Ag[0]);
+    fc = fc + f[0];
+    F[0] = mul(Ic, S[0]);
+    float H00 = dot(S[0], F[0]), t0 = dot(S[0], fc);
+    Hd[0] = H00; Hd[1] = H11; Hd[2] = H22;
+    float tb[3] = {t0, t1, t2};
+
+    // joint-space terms: damping, armature, servo, soft limits
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const KLink &L = link_of<BAKED>(C, k, i);
+        // position servo (quadruped.xml:10-37): force from the PRE-update activation
+        float force = L.kp * (act[i] - L.gear * q[i]) - L.kv * L.gear * qd[i];
+        bool clamped = (force <= L.force_lo) || (force >= L.force_hi);
+        force = fminf(fmaxf(force, L.force_lo), L.force_hi);
+        float dimp = L.damping + (clamped ? 0.f : L.kv * L.gear * L.gear);
+        float tau = L.gear * force - L.damping * qd[i];
+        // soft joint limits
+        float below = L.lo - q[i], above = q[i] - L.hi;
+        float pen = fmaxf(fmaxf(below, above), 0.f);
+        float bl = C.limit_b * fminf(pen * C.limit_inv_ramp, 1.f);   // damper ramps in: continuous torque
+        if (below > 0.f) {
+            float spring = C.limit_k * below;
+            float t = spring - bl * qd[i];
+            float be = bl;
+            if (t < 0.f) { t = 0.f; be = spring * rcp(qd[i]); }
+            tau += t;
+            dimp += be;
+        } else if (above > 0.f) {
+            float spring = C.limit_k * above;
+            float t = spring + bl * qd[i];
+            float be = bl;
+            if (t < 0.f) { t = 0.f; be = -spring * rcp(qd[i]); }
+            tau -= t;
+            dimp += be;
+        }
+        Hd[i] += L.armature + h * dimp;
+        bj[i] = tau - tb[i];
+    }
+}
+
+// Block elimination of one leg: LDL^T of the 3x3 joint block, Y = F H^-1 (6x3, stored as three
+// 6-vectors), u = H^-1 b; returns the Schur terms  YFt = Y F^T (symmetric 6x6)  and  Fu = F u.
+DEV void leg_eliminate(const SV F[3], const float Hd[3], float H01, float H02, float H12, const float bj[3], float Y0[6], float Y1[6],
+                       float Y2[6], float u[3], Sym6 &YFt, SV &Fu) {
+    float d0 = Hd[0], id0 = rcp(d0);
+    float l10 = H01 * id0, l20 = H02 * id0;
+    float d1 = fmaf(-l10, H01, Hd[1]), id1 = rcp(d1);
+    float t21 = fmaf(-l20, H01, H12);
+    float l21 = t21 * id1;
+    float d2 = fmaf(-l21, t21, fmaf(-l20, H02, Hd[2])), id2 = rcp(d2);
+    float Fr0[6] = {F[0].a.x, F[0].a.y, F[0].a.z, F[0].l.x, F[0].l.y, F[0].l.z};
+    float Fr1[6] = {F[1].a.x, F[1].a.y, F[1].a.z, F[1].l.x, F[1].l.y, F[1].l.z};
+    float Fr2[6] = {F[2].a.x, F[2].a.y, F[2].a.z, F[2].l.x, F[2].l.y, F[2].l.z};
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float z0 = Fr0[r];
+        float z1 = fmaf(-l10, z0, Fr1[r]);
+        float z2 = fmaf(-l21, z1, fmaf(-l20, z0, Fr2[r]));
+        float y2 = z2 * id2;
+        float y1 = fmaf(-l21, y2, z1 * id1);
+        float y0 = fmaf(-l20, y2, fmaf(-l10, y1, z0 * id0));
+        Y0[r] = y0; Y1[r] = y1; Y2[r] = y2;
+    }
+    {
+        float z0 = bj[0];
+        float z1 = fmaf(-l10, z0, bj[1]);
+        float z2 = fmaf(-l21, z1, fmaf(-l20, z0, bj[2]));
+        u[2] = z2 * id2;
+        u[1] = fmaf(-l21, u[2], z1 * id1);
+        u[0] = fmaf(-l20, u[2], fmaf(-l10, u[1], z0 * id0));
+    }
+#define YF(r, c) (Y0[r] * Fr0[c] + Y1[r] * Fr1[c] + Y2[r] * Fr2[c])
+    YFt.AA.xx = YF(0, 0); YFt.AA.yy = YF(1, 1); YFt.AA.zz = YF(2, 2);
+    YFt.AA.xy = YF(0, 1); YFt.AA.xz = YF(0, 2); YFt.AA.yz = YF(1, 2);
+    YFt.AL.r0 = v3(YF(0, 3), YF(0, 4), YF(0, 5));
+    YFt.AL.r1 = v3(YF(1, 3), YF(1, 4), YF(1, 5));
+    YFt.AL.r2 = v3(YF(2, 3), YF(2, 4), YF(2, 5));
+    YFt.LL.xx = YF(3, 3); YFt.LL.yy = YF(4, 4); YFt.LL.zz = YF(5, 5);
+    YFt.LL.xy = YF(3, 4); YFt.LL.xz = YF(3, 5); YFt.LL.yz = YF(4, 5);
+#undef YF
+    Fu.a = v3(Fr0[0] * u[0] + Fr1[0] * u[1] + Fr2[0] * u[2], Fr0[1] * u[0] + Fr1[1] * u[1] + Fr2[1] * u[2],
+              Fr0[2] * u[0] + Fr1[2] * u[1] + Fr2[2] * u[2]);
+    Fu.l = v3(Fr0[3] * u[0] + Fr1[3] * u[1] + Fr2[3] * u[2], Fr0[4] * u[0] + Fr1[4] * u[1] + Fr2[4] * u[2],
+              Fr0[5] * u[0] + Fr1[5] * u[1] + Fr2[5] * u[2]);
+}
+DEV void sub(Sym3 &a, const Sym3 &b) { a.xx -= b.xx; a.yy -= b.yy; a.zz -= b.zz; a.xy -= b.xy; a.xz -= b.xz; a.yz -= b.yz; }
+DEV void sub(Sym6 &a, const Sym6 &b) {
+    sub(a.AA, b.AA); sub(a.LL, b.LL);
+    a.AL.r0 = a.AL.r0 - b.AL.r0; a.AL.r1 = a.AL.r1 - b.AL.r1; a.AL.r2 = a.AL.r2 - b.AL.r2;
+}
+
+// 6x6 base solve  Ic0 x = b  by LDL^T, x = [d/dt w_b; classical acceleration of the FRAME origin]
+DEV void base_solve(const Sym6 &Ic0, SV rhs, float x6[6]) {
+    float A[6][6];
+    A[0][0] = Ic0.AA.xx; A[1][1] = Ic0.AA.yy; A[2][2] = Ic0.AA.zz;
+    A[1][0] = Ic0.AA.xy; A[2][0] = Ic0.AA.xz; A[2][1] = Ic0.AA.yz;
+    A[3][0] = Ic0.AL.r0.x; A[4][0] = Ic0.AL.r0.y; A[5][0] = Ic0.AL.r0.z;
+    A[3][1] = Ic0.AL.r1.x; A[4][1] = Ic0.AL.r1.y; A[5][1] = Ic0.AL.r1.z;
+    A[3][2] = Ic0.AL.r2.x; A[4][2] = Ic0.AL.r2.y; A[5][2] = Ic0.AL.r2.z;
+    A[3][3] = Ic0.LL.xx; A[4][4] = Ic0.LL.yy; A[5][5] = Ic0.LL.zz;
+    A[4][3] = Ic0.LL.xy; A[5][3] = Ic0.LL.xz; A[5][4] = Ic0.LL.yz;
+    float b[6] = {rhs.a.x, rhs.a.y, rhs.a.z, rhs.l.x, rhs.l.y, rhs.l.z};
+    // in-place LDL^T on the lower triangle (A[i][j], i >= j); L below the diagonal, 1/D kept apart
+    float dg[6], idg[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float ld[6];                      // L[j][t] * D[t]
+        float d = A[j][j];
+#pragma unroll
+        for (int t = 0; t < j; ++t) { ld[t] = A[j][t] * dg[t]; d = fmaf(-A[j][t], ld[t], d); }
+        dg[j] = d;
+        idg[j] = rcp(d);
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            float sacc = A[i][j];
+#pragma unroll
+            for (int t = 0; t < j; ++t) sacc = fmaf(-A[i][t], ld[t], sacc);
+            A[i][j] = sacc * idg[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int t = 0; t < i; ++t) b[i] = fmaf(-A[i][t], b[t], b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] *= idg[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+#pragma unroll
+        for (int t = i + 1; t < 6; ++t) b[i] = fmaf(-A[t][i], b[t], b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x6[i] = b[i];
+}
+
+// semi-implicit integration of the base: velocity, then position / quaternion with the NEW velocity
+DEV void base_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B) {
+    // d/dt v_world = R * (classical acceleration in FRAME axes)
+    V3 aw = fma3(acl.x, c.cx, fma3(acl.y, c.cy, acl.z * c.cz));
+    B.vw = fma3(h, aw, B.vw);
+    B.wb = fma3(h, wdot, B.wb);
+    B.pw = fma3(h, B.vw, B.pw);
+    // q <- q * exp(h w): half-angle series (|h w| / 2 stays far below 0.5 rad)
+    float hh = 0.5f * h;
+    float x2 = hh * hh * dot(B.wb, B.wb);
+    float sc = hh * fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 5040.f, 1.f / 120.f), -1.f / 6.f), 1.f);
+    float cw = fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 720.f, 1.f / 24.f), -0.5f), 1.f);
+    V3 dv = sc * B.wb;
+    float w = c.w, x = c.x, y = c.y, z = c.z;
+    float nw = w * cw - x * dv.x - y * dv.y - z * dv.z;
+    float nx = w * dv.x + x * cw + y * dv.z - z * dv.y;
+    float ny = w * dv.y - x * dv.z + y * cw + z * dv.x;
+    float nz = w * dv.z + x * dv.y - y * dv.x + z * cw;
+    float inv = rcp(__builtin_amdgcn_sqrtf(nw * nw + nx * nx + ny * ny + nz * nz));
+    B.qw = nw * inv; B.qx = nx * inv; B.qy = ny * inv; B.qz = nz * inv;
+}
 
 // ------------------------------------------------------------------------------------------
 // per-lane scratch columns in LDS: slot s of lane l lives at lds[s * 64 + l] (conflict-free)
@@ -219,284 +501,78 @@ DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V
 #define QG_LDS_SLOTS (48 + 21 * 4)
 #define QG_OBS_TILE_FLOATS (64 * 35)
 
-struct BaseState { V3 pw; float qw, qx, qy, qz; V3 vw; V3 wb; };
+struct SensorOut { float accel[3]; V3 pw, vw, wb, vb, xaxis, zaxis; };
 
-struct SensorOut { float accel[3]; V3 pw, vw, wb, vb, xaxis, zaxis; float jpos[12]; };
-
-// one physics substep for the env of this lane (mj_step of quadruped.py:165)
+// one physics substep for the env of this lane (mj_step of quadruped.py:165), one env per lane
 template <bool BAKED>
-DEV void substep(const KModel *__restrict__ Mp, float *__restrict__ lds, int lane, BaseState &B, bool want_sensors, SensorOut &so) {
+DEV void substep(const KModel *__restrict__ Mp, float *__restrict__ lds, int lane, BaseState &B, bool want_sensors, SensorOut &so,
+                 float *__restrict__ jpos_out) {
     const KModel &C = table<BAKED>(Mp);
-    const KModel *M = &C;
-    const float h = M->h;
+    const float h = C.h;
     // ---- A. base prelude -----------------------------------------------------------------
-    float qn = rcp(__builtin_amdgcn_sqrtf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz));
-    float w = B.qw * qn, x = B.qx * qn, y = B.qy * qn, z = B.qz * qn;
-    // R (FRAME -> world), stored by columns: cx, cy, cz are the FRAME axes in world coordinates
-    V3 cx = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y));
-    V3 cy = v3(2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x));
-    V3 cz = v3(2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y));
-    V3 n = v3(cx.z, cy.z, cz.z);                                   // world up in FRAME axes
-    V3 gw = ld3(M->g);
-    V3 gb = v3(dot(cx, gw), dot(cy, gw), dot(cz, gw));             // gravity in FRAME axes
-    V3 vb = v3(dot(cx, B.vw), dot(cy, B.vw), dot(cz, B.vw));       // base linear velocity in FRAME axes
-    SV V0 = {B.wb, vb};
-    // unknowns are (d/dt w_b, classical acceleration of the FRAME origin); with both zero the
-    // spatial acceleration of the FRAME is [0; -w x v - g]
-    SV A0 = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f) - cross(B.wb, vb) - gb};
-
+    const BaseCtx bc = base_prelude(C, B);
     if (want_sensors) {
-        so.pw = B.pw; so.vw = B.vw; so.wb = B.wb; so.vb = vb;
-        so.xaxis = cx; so.zaxis = cz;
+        so.pw = B.pw; so.vw = B.vw; so.wb = B.wb; so.vb = bc.vb;
+        so.xaxis = bc.cx; so.zaxis = bc.cz;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) so.jpos[j] = lds[LQ(j) * 64 + lane];
+        for (int j = 0; j < 12; ++j) jpos_out[j] = lds[LQ(j) * 64 + lane];
     }
-
-    Rigid I0 = {M->m0, ld3(M->h0), {M->I0[0], M->I0[1], M->I0[2], M->I0[3], M->I0[4], M->I0[5]}};
-    SV Iv0 = mul(I0, V0), Ia0 = mul(I0, A0);
-    SV p0;                                                          // bias force on the base rows
-    p0.a = Ia0.a + cross(V0.a, Iv0.a) + cross(V0.l, Iv0.l);
-    p0.l = Ia0.l + cross(V0.a, Iv0.l);
-    Sym6 Ic0 = sym6_of(I0);
+    SV p0;
+    Sym6 Ic0;
+    frame_body(C, bc, h, p0, Ic0);
     {
         Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
         SV fe;
-        body_contact<QGK_CP_FRAME>(M->cp0, E0, v3(0.f, 0.f, 0.f), B.pw.z, n, V0, M->contact_k, M->contact_c, M->contact_inv_ramp,
-                                   M->contact_margin, M->contact_mu, h, fe, Ic0);
+        body_contact<QGK_CP_FRAME>(C.cp0, E0, v3(0.f, 0.f, 0.f), B.pw.z, bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp,
+                                   C.contact_margin, C.contact_mu, h, fe, Ic0);
         p0.a = p0.a - fe.a;
         p0.l = p0.l - fe.l;
     }
-    // free-joint damping and armature act on all six base DoFs (quadruped.xml:9,62-63)
-    {
-        float dg = M->free_armature + h * M->free_damping;
-        Ic0.AA.xx += dg; Ic0.AA.yy += dg; Ic0.AA.zz += dg;
-        Ic0.LL.xx += dg; Ic0.LL.yy += dg; Ic0.LL.zz += dg;
-        p0.a = fma3(M->free_damping, V0.a, p0.a);
-        p0.l = fma3(M->free_damping, V0.l, p0.l);
-    }
-    SV rhs0 = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};               // accumulates -Y b of the legs
+    SV rhs0 = {v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 0.f)};               // accumulates -F u of the legs
 
     // ---- B. legs: dynamics terms and elimination into the base block ---------------------
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
-        Fr Ep = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-        V3 pp = v3(0.f, 0.f, 0.f);
-        SV vp = V0, ap = A0;
-        SV S[3], f[3];
-        Sym6 Ag[3];
-        float qd[3];
+        float q[3], qd[3], act[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const KLink &L = link_of<BAKED>(C, k, i);
-            const KLink &Lm = (i == 0) ? C.link[3 * k] : L;   // the fema's mounting transform differs per leg
-            const int j = 3 * k + i;
-            float th = lds[LQ(j) * 64 + lane] - L.ref;      // rotation applied = qpos - ref
-            qd[i] = lds[LQD(j) * 64 + lane];
-            float sn, cs;
-            sincos_f(th, sn, cs);
-            V3 p = pp + rot(Ep, ld3(Lm.pos));
-            V3 tx = fma3(Lm.Q[0], Ep.ex, fma3(Lm.Q[3], Ep.ey, Lm.Q[6] * Ep.ez));
-            V3 ty = fma3(Lm.Q[1], Ep.ex, fma3(Lm.Q[4], Ep.ey, Lm.Q[7] * Ep.ez));
-            V3 tz = fma3(Lm.Q[2], Ep.ex, fma3(Lm.Q[5], Ep.ey, Lm.Q[8] * Ep.ez));
-            Fr E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
-            S[i].a = E.ez;
-            S[i].l = cross(p, E.ez);
-            SV v = {fma3(qd[i], S[i].a, vp.a), fma3(qd[i], S[i].l, vp.l)};
-            // a = a_parent + (v x S) qd
-            SV a;
-            a.a = fma3(qd[i], cross(v.a, S[i].a), ap.a);
-            a.l = fma3(qd[i], cross(v.a, S[i].l) + cross(v.l, S[i].a), ap.l);
-            // rigid inertia of the link about the FRAME origin, FRAME axes
-            Rigid Bi;
-            Bi.m = L.mass;
-            V3 c = p + rot(E, ld3(L.ipos));
-            Bi.h = L.mass * c;
-            {
-                V3 ux = fma3(L.inertia[0], E.ex, fma3(L.inertia[3], E.ey, L.inertia[4] * E.ez));
-                V3 uy = fma3(L.inertia[3], E.ex, fma3(L.inertia[1], E.ey, L.inertia[5] * E.ez));
-                V3 uz = fma3(L.inertia[4], E.ex, fma3(L.inertia[5], E.ey, L.inertia[2] * E.ez));
-                float hc = dot(Bi.h, c);
-                Bi.I.xx = fmaf(ux.x, E.ex.x, fmaf(uy.x, E.ey.x, uz.x * E.ez.x)) + hc - Bi.h.x * c.x;
-                Bi.I.yy = fmaf(ux.y, E.ex.y, fmaf(uy.y, E.ey.y, uz.y * E.ez.y)) + hc - Bi.h.y * c.y;
-                Bi.I.zz = fmaf(ux.z, E.ex.z, fmaf(uy.z, E.ey.z, uz.z * E.ez.z)) + hc - Bi.h.z * c.z;
-                Bi.I.xy = fmaf(ux.x, E.ex.y, fmaf(uy.x, E.ey.y, uz.x * E.ez.y)) - Bi.h.x * c.y;
-                Bi.I.xz = fmaf(ux.x, E.ex.z, fmaf(uy.x, E.ey.z, uz.x * E.ez.z)) - Bi.h.x * c.z;
-                Bi.I.yz = fmaf(ux.y, E.ex.z, fmaf(uy.y, E.ey.z, uz.y * E.ez.z)) - Bi.h.y * c.z;
-            }
-            SV Iv = mul(Bi, v), Ia = mul(Bi, a);
-            f[i].a = Ia.a + cross(v.a, Iv.a) + cross(v.l, Iv.l);
-            f[i].l = Ia.l + cross(v.a, Iv.l);
-            Ag[i] = sym6_of(Bi);
-            SV fe;
-            body_contact<QGK_CP_LINK>(L.cp, E, p, B.pw.z + dot(n, p), n, v, M->contact_k, M->contact_c, M->contact_inv_ramp,
-                                      M->contact_margin, M->contact_mu, h, fe, Ag[i]);
-            f[i].a = f[i].a - fe.a;
-            f[i].l = f[i].l - fe.l;
-            Ep = E; pp = p; vp = v; ap = a;
+            q[i] = lds[LQ(3 * k + i) * 64 + lane];
+            qd[i] = lds[LQD(3 * k + i) * 64 + lane];
+            act[i] = lds[LACT(3 * k + i) * 64 + lane];
         }
-        // backward pass: composite inertias (mass-matrix columns) and bias torques
-        Sym6 Ic = Ag[2];
-        SV fc = f[2];
-        SV F2 = mul(Ic, S[2]);
-        float H22 = dot(S[2], F2), H12 = dot(S[1], F2), H02 = dot(S[0], F2), t2 = dot(S[2], fc);
-        add(Ic, Ag[1]);
-        fc = fc + f[1];
-        SV F1 = mul(Ic, S[1]);
-        float H11 = dot(S[1], F1), H01 = dot(S[0], F1), t1 = dot(S[1], fc);
-        add(Ic, Ag[0]);
-        fc = fc + f[0];
-        SV F0 = mul(Ic, S[0]);
-        float H00 = dot(S[0], F0), t0 = dot(S[0], fc);
+        Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+        Sym6 Ic, YFt;
+        SV fc, F[3], Fu;
+        float Hd[3], H01, H02, H12, bj[3], Y0[6], Y1[6], Y2[6], u[3];
+        leg_pass<BAKED, false>(C, k, E0, q, qd, act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+        leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         add(Ic0, Ic);
+        sub(Ic0, YFt);
         p0 = p0 + fc;
-
-        // joint-space terms: damping, armature, servo, soft limits
-        float bj[3], Hd[3] = {H00, H11, H22}, tb[3] = {t0, t1, t2};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const KLink &L = link_of<BAKED>(C, k, i);
-            const int j = 3 * k + i;
-            float q = lds[LQ(j) * 64 + lane];
-            float act = lds[LACT(j) * 64 + lane];
-            // position servo (quadruped.xml:10-37): force from the PRE-update activation
-            float force = L.kp * (act - L.gear * q) - L.kv * L.gear * qd[i];
-            bool clamped = (force <= L.force_lo) || (force >= L.force_hi);
-            force = fminf(fmaxf(force, L.force_lo), L.force_hi);
-            float dimp = L.damping + (clamped ? 0.f : L.kv * L.gear * L.gear);
-            float tau = L.gear * force - L.damping * qd[i];
-            // soft joint limits
-            float below = L.lo - q, above = q - L.hi;
-            float pen = fmaxf(fmaxf(below, above), 0.f);
-            float bl = M->limit_b * fminf(pen * M->limit_inv_ramp, 1.f);   // damper ramps in: continuous torque
-            if (below > 0.f) {
-                float spring = M->limit_k * below;
-                float t = spring - bl * qd[i];
-                float be = bl;
-                if (t < 0.f) { t = 0.f; be = spring * rcp(qd[i]); }
-                tau += t;
-                dimp += be;
-            } else if (above > 0.f) {
-                float spring = M->limit_k * above;
-                float t = spring + bl * qd[i];
-                float be = bl;
-                if (t < 0.f) { t = 0.f; be = -spring * rcp(qd[i]); }
-                tau -= t;
-                dimp += be;
-            }
-            Hd[i] += L.armature + h * dimp;
-            bj[i] = tau - tb[i];
-        }
-        // LDL^T of the leg block [hip, knee, ankle]
-        float d0 = Hd[0], id0 = rcp(d0);
-        float l10 = H01 * id0, l20 = H02 * id0;
-        float d1 = fmaf(-l10, H01, Hd[1]), id1 = rcp(d1);
-        float t21 = fmaf(-l20, H01, H12);
-        float l21 = t21 * id1;
-        float d2 = fmaf(-l21, t21, fmaf(-l20, H02, Hd[2])), id2 = rcp(d2);
-        // y = H^-1 r for r = rows of F (6) and r = b
-        float Fr0[6] = {F0.a.x, F0.a.y, F0.a.z, F0.l.x, F0.l.y, F0.l.z};
-        float Fr1[6] = {F1.a.x, F1.a.y, F1.a.z, F1.l.x, F1.l.y, F1.l.z};
-        float Fr2[6] = {F2.a.x, F2.a.y, F2.a.z, F2.l.x, F2.l.y, F2.l.z};
-        float Y0[6], Y1[6], Y2[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            float z0 = Fr0[r];
-            float z1 = fmaf(-l10, z0, Fr1[r]);
-            float z2 = fmaf(-l21, z1, fmaf(-l20, z0, Fr2[r]));
-            float y2 = z2 * id2;
-            float y1 = fmaf(-l21, y2, z1 * id1);
-            float y0 = fmaf(-l20, y2, fmaf(-l10, y1, z0 * id0));
-            Y0[r] = y0; Y1[r] = y1; Y2[r] = y2;
-        }
-        float u0, u1, u2;
-        {
-            float z0 = bj[0];
-            float z1 = fmaf(-l10, z0, bj[1]);
-            float z2 = fmaf(-l21, z1, fmaf(-l20, z0, bj[2]));
-            u2 = z2 * id2;
-            u1 = fmaf(-l21, u2, z1 * id1);
-            u0 = fmaf(-l20, u2, fmaf(-l10, u1, z0 * id0));
-        }
-        // Schur complement: Ic0 -= Y F^T (symmetric), rhs0 -= F u
-        {
-#define YF(r, c) (Y0[r] * Fr0[c] + Y1[r] * Fr1[c] + Y2[r] * Fr2[c])
-            Ic0.AA.xx -= YF(0, 0); Ic0.AA.yy -= YF(1, 1); Ic0.AA.zz -= YF(2, 2);
-            Ic0.AA.xy -= YF(0, 1); Ic0.AA.xz -= YF(0, 2); Ic0.AA.yz -= YF(1, 2);
-            Ic0.AL.r0.x -= YF(0, 3); Ic0.AL.r0.y -= YF(0, 4); Ic0.AL.r0.z -= YF(0, 5);
-            Ic0.AL.r1.x -= YF(1, 3); Ic0.AL.r1.y -= YF(1, 4); Ic0.AL.r1.z -= YF(1, 5);
-            Ic0.AL.r2.x -= YF(2, 3); Ic0.AL.r2.y -= YF(2, 4); Ic0.AL.r2.z -= YF(2, 5);
-            Ic0.LL.xx -= YF(3, 3); Ic0.LL.yy -= YF(4, 4); Ic0.LL.zz -= YF(5, 5);
-            Ic0.LL.xy -= YF(3, 4); Ic0.LL.xz -= YF(3, 5); Ic0.LL.yz -= YF(4, 5);
-#undef YF
-            rhs0.a.x -= Fr0[0] * u0 + Fr1[0] * u1 + Fr2[0] * u2;
-            rhs0.a.y -= Fr0[1] * u0 + Fr1[1] * u1 + Fr2[1] * u2;
-            rhs0.a.z -= Fr0[2] * u0 + Fr1[2] * u1 + Fr2[2] * u2;
-            rhs0.l.x -= Fr0[3] * u0 + Fr1[3] * u1 + Fr2[3] * u2;
-            rhs0.l.y -= Fr0[4] * u0 + Fr1[4] * u1 + Fr2[4] * u2;
-            rhs0.l.z -= Fr0[5] * u0 + Fr1[5] * u1 + Fr2[5] * u2;
-        }
+        rhs0.a = rhs0.a - Fu.a;
+        rhs0.l = rhs0.l - Fu.l;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             lds[LY(k, r) * 64 + lane] = Y0[r];
             lds[LY(k, 6 + r) * 64 + lane] = Y1[r];
             lds[LY(k, 12 + r) * 64 + lane] = Y2[r];
         }
-        lds[LY(k, 18) * 64 + lane] = u0;
-        lds[LY(k, 19) * 64 + lane] = u1;
-        lds[LY(k, 20) * 64 + lane] = u2;
+        lds[LY(k, 18) * 64 + lane] = u[0];
+        lds[LY(k, 19) * 64 + lane] = u[1];
+        lds[LY(k, 20) * 64 + lane] = u[2];
     }
 
-    // ---- C. base solve: Ic0 x = rhs0 - p0, x = [d/dt w_b; classical acceleration] ---------
+    // ---- C. base solve: Ic0 x = rhs0 - p0 ----------------------------------------------------
     float x6[6];
     {
-        float A[6][6];
-        A[0][0] = Ic0.AA.xx; A[1][1] = Ic0.AA.yy; A[2][2] = Ic0.AA.zz;
-        A[1][0] = Ic0.AA.xy; A[2][0] = Ic0.AA.xz; A[2][1] = Ic0.AA.yz;
-        A[3][0] = Ic0.AL.r0.x; A[4][0] = Ic0.AL.r0.y; A[5][0] = Ic0.AL.r0.z;
-        A[3][1] = Ic0.AL.r1.x; A[4][1] = Ic0.AL.r1.y; A[5][1] = Ic0.AL.r1.z;
-        A[3][2] = Ic0.AL.r2.x; A[4][2] = Ic0.AL.r2.y; A[5][2] = Ic0.AL.r2.z;
-        A[3][3] = Ic0.LL.xx; A[4][4] = Ic0.LL.yy; A[5][5] = Ic0.LL.zz;
-        A[4][3] = Ic0.LL.xy; A[5][3] = Ic0.LL.xz; A[5][4] = Ic0.LL.yz;
-        float b[6] = {rhs0.a.x - p0.a.x, rhs0.a.y - p0.a.y, rhs0.a.z - p0.a.z,
-                      rhs0.l.x - p0.l.x, rhs0.l.y - p0.l.y, rhs0.l.z - p0.l.z};
-        // in-place LDL^T on the lower triangle (A[i][j], i >= j); L below the diagonal, 1/D kept apart
-        float dg[6], idg[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float ld[6];                      // L[j][t] * D[t]
-            float d = A[j][j];
-#pragma unroll
-            for (int t = 0; t < j; ++t) { ld[t] = A[j][t] * dg[t]; d = fmaf(-A[j][t], ld[t], d); }
-            dg[j] = d;
-            idg[j] = rcp(d);
-#pragma unroll
-            for (int i = j + 1; i < 6; ++i) {
-                float s = A[i][j];
-#pragma unroll
-                for (int t = 0; t < j; ++t) s = fmaf(-A[i][t], ld[t], s);
-                A[i][j] = s * idg[j];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int t = 0; t < i; ++t) b[i] = fmaf(-A[i][t], b[t], b[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) b[i] *= idg[i];
-#pragma unroll
-        for (int i = 5; i >= 0; --i) {
-#pragma unroll
-            for (int t = i + 1; t < 6; ++t) b[i] = fmaf(-A[t][i], b[t], b[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) x6[i] = b[i];
+        SV b = {rhs0.a - p0.a, rhs0.l - p0.l};
+        base_solve(Ic0, b, x6);
     }
     V3 wdot = v3(x6[0], x6[1], x6[2]);
     V3 acl = v3(x6[3], x6[4], x6[5]);
     if (want_sensors) {
         // accelerometer (quadruped.xml:200): proper acceleration in the site frame = a_c - g_b
-        so.accel[0] = acl.x - gb.x; so.accel[1] = acl.y - gb.y; so.accel[2] = acl.z - gb.z;
+        so.accel[0] = acl.x - bc.gb.x; so.accel[1] = acl.y - bc.gb.y; so.accel[2] = acl.z - bc.gb.z;
     }
 
     // ---- D. legs: back-substitution, hinge integration, servo filter ---------------------
@@ -518,30 +594,29 @@ DEV void substep(const KModel *__restrict__ Mp, float *__restrict__ lds, int lan
     }
 
     // ---- E. base integration ---------------------------------------------------------------
-    // d/dt v_world = R * (classical acceleration in FRAME axes)
-    V3 aw = fma3(acl.x, cx, fma3(acl.y, cy, acl.z * cz));
-    B.vw = fma3(h, aw, B.vw);
-    B.wb = fma3(h, wdot, B.wb);
-    B.pw = fma3(h, B.vw, B.pw);
-    {
-        // q <- q * exp(h w): half-angle series (|h w| / 2 stays far below 0.5 rad)
-        float hh = 0.5f * h;
-        float x2 = hh * hh * dot(B.wb, B.wb);
-        float sc = hh * fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 5040.f, 1.f / 120.f), -1.f / 6.f), 1.f);
-        float cw = fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 720.f, 1.f / 24.f), -0.5f), 1.f);
-        V3 dv = sc * B.wb;
-        float nw = w * cw - x * dv.x - y * dv.y - z * dv.z;
-        float nx = w * dv.x + x * cw + y * dv.z - z * dv.y;
-        float ny = w * dv.y - x * dv.z + y * cw + z * dv.x;
-        float nz = w * dv.z + x * dv.y - y * dv.x + z * cw;
-        float inv = rcp(__builtin_amdgcn_sqrtf(nw * nw + nx * nx + ny * ny + nz * nz));
-        B.qw = nw * inv; B.qx = nx * inv; B.qy = ny * inv; B.qz = nz * inv;
+    base_integrate(bc, h, wdot, acl, B);
+}
+
+// rows of the output tile: the 33-value sensordata (quadruped.xml:174-217) or the 21-value pack
+DEV void write_obs_row(float *r, int od, const float *jpos, const SensorOut &so) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) r[j] = jpos[j];
+    r[12] = so.accel[0]; r[13] = so.accel[1]; r[14] = so.accel[2];
+    r[15] = so.wb.x; r[16] = so.wb.y; r[17] = so.wb.z;
+    if (od == 33) {
+        r[18] = so.pw.x; r[19] = so.pw.y; r[20] = so.pw.z;
+        r[21] = so.vw.x; r[22] = so.vw.y; r[23] = so.vw.z;
+        r[24] = so.xaxis.x; r[25] = so.xaxis.y; r[26] = so.xaxis.z;
+        r[27] = so.zaxis.x; r[28] = so.zaxis.y; r[29] = so.zaxis.z;
+        r[30] = so.vb.x; r[31] = so.vb.y; r[32] = so.vb.z;
+    } else {
+        r[18] = so.vb.x; r[19] = so.vb.y; r[20] = so.vb.z;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// env-step kernel: one launch = frame_skip substeps + sensor pack + rewards + terminations
-// (+ auto-reset) for every env.  grid = ceil(n / 64) workgroups of one wave.
+// env-step kernel, ONE ENV PER LANE: one launch = frame_skip substeps + sensor pack + rewards +
+// terminations (+ auto-reset) for every env.  grid = ceil(n / 64) workgroups of one wave.
 // ------------------------------------------------------------------------------------------
 template <bool BAKED>
 __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P) {
@@ -582,17 +657,18 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
 
     // ---- frame_skip physics substeps (quadruped.py:163-165) ----------------------------------
     SensorOut so;
+    float jpos[12];
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep<BAKED>(Mp, lds, lane, B, lag && (s == fs - 1), so);
+    for (int s = 0; s < fs; ++s) substep<BAKED>(Mp, lds, lane, B, lag && (s == fs - 1), so, jpos);
     nstep += fs;
     if (!lag) {   // un-lagged sensors: one extra forward pass on a scratch copy of the state
         BaseState B2 = B;
         float keep[36];
 #pragma unroll
         for (int j = 0; j < 36; ++j) keep[j] = lds[j * 64 + lane];
-        substep<BAKED>(Mp, lds, lane, B2, true, so);
+        substep<BAKED>(Mp, lds, lane, B2, true, so, jpos);
 #pragma unroll
         for (int j = 0; j < 36; ++j) lds[j * 64 + lane] = keep[j];
     }
@@ -610,19 +686,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
     const int row = P.packed ? od + 2 : od;
     {
         float *r = tile + lane * row;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) r[j] = so.jpos[j];
-        r[12] = so.accel[0]; r[13] = so.accel[1]; r[14] = so.accel[2];
-        r[15] = so.wb.x; r[16] = so.wb.y; r[17] = so.wb.z;
-        if (od == 33) {
-            r[18] = so.pw.x; r[19] = so.pw.y; r[20] = so.pw.z;
-            r[21] = so.vw.x; r[22] = so.vw.y; r[23] = so.vw.z;
-            r[24] = so.xaxis.x; r[25] = so.xaxis.y; r[26] = so.xaxis.z;
-            r[27] = so.zaxis.x; r[28] = so.zaxis.y; r[29] = so.zaxis.z;
-            r[30] = so.vb.x; r[31] = so.vb.y; r[32] = so.vb.z;
-        } else {
-            r[18] = so.vb.x; r[19] = so.vb.y; r[20] = so.vb.z;
-        }
+        write_obs_row(r, od, jpos, so);
         if (P.packed) { r[od] = reward; r[od + 1] = done ? 1.f : 0.f; }
     }
     __syncthreads();
@@ -672,6 +736,226 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
         if (P.track_ctrl) {
 #pragma unroll
             for (int j = 0; j < 12; ++j) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// env-step kernel, ONE LEG PER LANE: the four lanes 4e..4e+3 of a quad share env e, lane k owns
+// leg k (and a quarter of the FRAME's contact points); the base prelude, the 6x6 base solve and
+// the base integration run redundantly in all four lanes; the leg contributions to the base
+// block (Schur complements, 33 numbers) are summed over the quad with DPP quad_perm moves --
+// no LDS, no run-time indexed arrays.  A wave carries 16 envs, so 4096 envs fill 256 waves
+// instead of 64: at batch sizes that cannot fill the chip with one env per lane this cuts the
+// instructions per wave (= the time, a lone wave issues one VALU instruction per 4 cycles) ~3.5x.
+// Needs the default (baked) robot: the legs are quarter-turn copies of one another.
+// ------------------------------------------------------------------------------------------
+template <int CTRL> DEV float dpp_quad(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over the 4 lanes of a quad; every lane gets the bitwise identical result ((a+b)+(c+d), commutative)
+DEV float quad_sum(float x) {
+    x += dpp_quad<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_quad<0x4E>(x);   // quad_perm [2,3,0,1]
+    return x;
+}
+DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+DEV void quad_sum(Sym3 &a) { a.xx = quad_sum(a.xx); a.yy = quad_sum(a.yy); a.zz = quad_sum(a.zz); a.xy = quad_sum(a.xy); a.xz = quad_sum(a.xz); a.yz = quad_sum(a.yz); }
+DEV void quad_sum(Sym6 &a) { quad_sum(a.AA); quad_sum(a.LL); a.AL.r0 = quad_sum(a.AL.r0); a.AL.r1 = quad_sum(a.AL.r1); a.AL.r2 = quad_sum(a.AL.r2); }
+
+struct LegState { float q[3], qd[3], act[3], u[3]; };
+
+DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_sensors, SensorOut &so, float jpos[3]) {
+    const KModel &C = QG_BAKED_MODEL;
+    const float h = C.h;
+    const BaseCtx bc = base_prelude(C, B);
+    if (want_sensors) {
+        so.pw = B.pw; so.vw = B.vw; so.wb = B.wb; so.vb = bc.vb;
+        so.xaxis = bc.cx; so.zaxis = bc.cz;
+        jpos[0] = L.q[0]; jpos[1] = L.q[1]; jpos[2] = L.q[2];
+    }
+    SV p0;
+    Sym6 Ic0;
+    frame_body(C, bc, h, p0, Ic0);
+    {   // FRAME contact: this lane evaluates its quarter turn of the three base sample points
+        float wsum = 0.f;
+        V3 s = v3(0.f, 0.f, 0.f);
+        float zb = C.contact_margin - B.pw.z;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            V3 r0 = ld3(C.cp0[4 * o]);
+            V3 r = v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z);
+            contact_point(r, bc.n, zb, wsum, s);
+        }
+        wsum = quad_sum(wsum);
+        s = quad_sum(s);
+        Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+        SV fe;
+        contact_finish(wsum, s, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
+        p0.a = p0.a - fe.a;
+        p0.l = p0.l - fe.l;
+    }
+    // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
+    Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
+    Sym6 Ic, YFt;
+    SV fc, F[3], Fu;
+    float Hd[3], H01, H02, H12, bj[3], Y0[6], Y1[6], Y2[6], u[3];
+    leg_pass<true, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+    leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
+    sub(Ic, YFt);                       // this leg's Schur complement
+    quad_sum(Ic);
+    fc.a = quad_sum(fc.a); fc.l = quad_sum(fc.l);
+    Fu.a = quad_sum(Fu.a); Fu.l = quad_sum(Fu.l);
+    add(Ic0, Ic);
+    float x6[6];
+    {
+        SV b = {v3(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a, v3(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l};
+        base_solve(Ic0, b, x6);
+    }
+    V3 wdot = v3(x6[0], x6[1], x6[2]);
+    V3 acl = v3(x6[3], x6[4], x6[5]);
+    if (want_sensors) {
+        so.accel[0] = acl.x - bc.gb.x; so.accel[1] = acl.y - bc.gb.y; so.accel[2] = acl.z - bc.gb.z;
+    }
+    // back-substitution and integration of this lane's three hinges
+    const float *Y[3] = {Y0, Y1, Y2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = u[i];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc = fmaf(-Y[i][r], x6[r], acc);
+        L.qd[i] = fmaf(h, acc, L.qd[i]);
+        L.q[i] = fmaf(h, L.qd[i], L.q[i]);
+        L.act[i] = fmaf(L.u[i] - L.act[i], C.link[i].act_decay, L.act[i]);
+    }
+    base_integrate(bc, h, wdot, acl, B);
+}
+
+#define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
+
+__global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel_quad(const KTask *__restrict__ T, KStepArgs P) {
+    const KModel &C = QG_BAKED_MODEL;
+    __shared__ float tile[QGK_QUAD_ENVS * 35];
+    const int lane = threadIdx.x;
+    const int k = lane & 3;                         // leg of this lane
+    const int el = lane >> 2;                       // env within the wave
+    const int env0 = blockIdx.x * QGK_QUAD_ENVS;
+    const int n = P.n;
+    const bool live = env0 + el < n;
+    const int env = live ? env0 + el : n - 1;       // tail quads shadow the last env; their stores are masked
+    // quarter turn of this lane's leg: (cos, sin)(90 deg * k)
+    const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
+    const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
+
+    BaseState B;
+    B.pw = v3(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
+    B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
+    B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
+    B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    int nstep = P.st.nstep[env];
+    LegState L;
+    float aclip[3];
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = 3 * k + i;
+        float a = fminf(fmaxf(P.actions[(size_t)env * 12 + j], -1.f), 1.f);    // quadruped.py:160
+        aclip[i] = a;
+        ssq = fmaf(a, a, ssq);
+        L.u[i] = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
+        L.q[i] = P.st.qpos[(7 + j) * n + env];
+        L.qd[i] = P.st.qvel[(6 + j) * n + env];
+        L.act[i] = P.st.act[j * n + env];
+    }
+    ssq = quad_sum(ssq);
+
+    SensorOut so;
+    float jpos[3];
+    const int fs = T->frame_skip;
+    const bool lag = T->sensor_lag != 0;
+#pragma unroll 1
+    for (int s = 0; s < fs; ++s) substep_quad(cm, sm, B, L, lag && (s == fs - 1), so, jpos);
+    nstep += fs;
+    if (!lag) {
+        BaseState B2 = B;
+        LegState L2 = L;
+        substep_quad(cm, sm, B2, L2, true, so, jpos);
+    }
+
+    float c_fwd = T->w_forward * B.vw.x;
+    float c_ctl = T->w_ctrl * ssq;
+    float c_alive = T->alive_bonus;
+    float reward = c_fwd + c_ctl + c_alive;
+    bool done = nstep >= T->limit_substeps;
+    if (T->use_fall) done = done || (B.pw.z < T->fall_height);
+
+    const int od = T->obs_mode == 1 ? 21 : 33;
+    const int row = P.packed ? od + 2 : od;
+    {
+        float *r = tile + el * row;
+        r[3 * k + 0] = jpos[0]; r[3 * k + 1] = jpos[1]; r[3 * k + 2] = jpos[2];
+        if (k == 0) {
+            r[12] = so.accel[0]; r[13] = so.accel[1]; r[14] = so.accel[2];
+            r[15] = so.wb.x; r[16] = so.wb.y; r[17] = so.wb.z;
+            if (od == 33) {
+                r[18] = so.pw.x; r[19] = so.pw.y; r[20] = so.pw.z;
+                r[21] = so.vw.x; r[22] = so.vw.y; r[23] = so.vw.z;
+                r[24] = so.xaxis.x; r[25] = so.xaxis.y; r[26] = so.xaxis.z;
+                r[27] = so.zaxis.x; r[28] = so.zaxis.y; r[29] = so.zaxis.z;
+                r[30] = so.vb.x; r[31] = so.vb.y; r[32] = so.vb.z;
+            } else {
+                r[18] = so.vb.x; r[19] = so.vb.y; r[20] = so.vb.z;
+            }
+            if (P.packed) { r[od] = reward; r[od + 1] = done ? 1.f : 0.f; }
+        }
+    }
+    __syncthreads();
+    {
+        const int live_envs = min(QGK_QUAD_ENVS, n - env0);
+        const int total = live_envs * row;
+        float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
+        for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+    }
+    const bool lead = live && k == 0;
+    if (lead && !P.packed) {
+        P.reward[env] = reward;
+        P.done[env] = done ? 1 : 0;
+    }
+    if (lead && P.comps) {
+        P.comps[(size_t)env * 3 + 0] = c_fwd;
+        P.comps[(size_t)env * 3 + 1] = c_ctl;
+        P.comps[(size_t)env * 3 + 2] = c_alive;
+    }
+
+    const bool rst = done && T->auto_reset;
+    if (rst) {
+        B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+        B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+        if (T->reset_flags & 1u) {
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, P.step_index);
+            float sn, cs;
+            sincos_f(0.5f * a, sn, cs);
+            B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+        }
+        B.vw = v3(0.f, 0.f, 0.f);
+        B.wb = v3(0.f, 0.f, 0.f);
+        nstep = 0;
+    }
+    if (lead) {
+        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
+        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
+        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
+        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
+        P.st.nstep[env] = nstep;
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = 3 * k + i;
+            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : L.q[i];
+            P.st.qvel[(6 + j) * n + env] = rst ? 0.f : L.qd[i];
+            P.st.act[j * n + env] = rst ? 0.f : L.act[i];
+            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
         }
     }
 }

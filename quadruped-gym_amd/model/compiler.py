@@ -339,6 +339,12 @@ def compile_mjcf(scene_path, mesh_inertia="convex"):
         hv, _ = hull_faces(cloud)
         if b["parent"] < 0:
             cps = select_contact_points(cloud[hv], CP_FRAME, fold=4)
+            # exact 4-fold orbits (3 base points x 4 quarter turns, stored orbit-major): the mesh is symmetric
+            # only to its 1e-6 vertex resolution; the one-leg-per-lane kernel rotates the base points itself
+            base_pts = cps[[0, 4, 8]]
+            quarter = [np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1.0]]), np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]]),
+                       np.array([[-1, 0, 0], [0, -1, 0], [0, 0, 1.0]]), np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])]
+            cps = np.array([R @ bp for bp in base_pts for R in quarter])
         else:
             cps = select_contact_points(cloud[hv], CP_LINK)
         out_bodies.append(dict(name=b["name"], parent=b["parent"], pos=b["pos"], quat=b["quat"], mass=mass,

@@ -114,6 +114,14 @@ class BatchedSim:
               "qg_time_step_kernel")
         return float(ms.value)
 
+    def set_mapping(self, mapping: int):
+        """``_abi.MAP_AUTO`` / ``MAP_LANE`` (one env per lane) / ``MAP_QUAD`` (one leg per lane)."""
+        check(self._lib.qg_set_mapping(self._h, int(mapping)), "qg_set_mapping")
+
+    @property
+    def mapping(self) -> int:
+        return int(self._lib.qg_get_mapping(self._h))
+
     def set_track_ctrl(self, on: bool):
         check(self._lib.qg_set_track_ctrl(self._h, 1 if on else 0), "qg_set_track_ctrl")
 

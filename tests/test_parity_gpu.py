@@ -48,12 +48,19 @@ def gold():
     return dict(np.load(GOLD))
 
 
+MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD}
+
+
+@pytest.mark.parametrize("mapping", ["lane", "quad"])
 @pytest.mark.parametrize("case", ["A", "B"])
-def test_step_matches_golden_vectors(gold, case):
+def test_step_matches_golden_vectors(gold, case, mapping):
+    """Both work mappings of the step kernel (one env per lane / one leg per lane) against the fixture."""
     from quadruped_gym_amd.sim import BatchedSim
     task = configure(_abi.default_task(), case)
     n = len(gold["qpos"])
     sim = BatchedSim(n, task=task)
+    sim.set_mapping(MAPPINGS[mapping])
+    assert sim.mapping == MAPPINGS[mapping]
     sim.set_state(gold["qpos"], gold["qvel"], gold["act"], None, gold["nstep"])
     obs, rew, done, comps = sim.step(gold["actions"], want_components=True)
     q1, v1, a1, c1, n1 = sim.get_state()
@@ -78,7 +85,8 @@ def test_step_matches_golden_vectors(gold, case):
     sim.close()
 
 
-def test_step_matches_oracle_on_fresh_states(oracle):
+@pytest.mark.parametrize("mapping", ["lane", "quad"])
+def test_step_matches_oracle_on_fresh_states(oracle, mapping):
     """Seeded states the fixture does not hold, through the device-pointer entry points."""
     import torch
     from quadruped_gym_amd.sim import BatchedSim
@@ -96,6 +104,7 @@ def test_step_matches_oracle_on_fresh_states(oracle):
     q_o, v_o, a_o, _, n_o = b.get_state()
 
     sim = BatchedSim(n, task=configure(_abi.default_task(), "A"))
+    sim.set_mapping(MAPPINGS[mapping])
     sim.set_state(qpos, qvel, act, None, nstep)
     dev = torch.device("cuda:0")
     a_d = torch.from_numpy(actions).to(dev)
@@ -197,7 +206,8 @@ def test_random_yaw_reset_matches_oracle_stream(oracle):
     sim.close()
 
 
-def test_time_limit_terminates_and_auto_reset():
+@pytest.mark.parametrize("mapping", ["lane", "quad"])
+def test_time_limit_terminates_and_auto_reset(mapping):
     """`time >= max_time` is reported as terminated on the exact substep the f64-accumulated clock
     crosses it (quadruped.py:149-151); with auto_reset the env restarts inside the same launch."""
     from quadruped_gym_amd.sim import BatchedSim
@@ -205,6 +215,7 @@ def test_time_limit_terminates_and_auto_reset():
     task.max_time = 0.05           # 25 substeps -> 7th env-step at frame_skip 4 (28 >= 25... first >= is step 7)
     task.auto_reset = 1
     sim = BatchedSim(70, task=task)
+    sim.set_mapping(MAPPINGS[mapping])
     lim = sim.limit_substeps
     a = np.zeros((70, 12), np.float32)
     k_done = None
@@ -221,13 +232,15 @@ def test_time_limit_terminates_and_auto_reset():
     sim.close()
 
 
-def test_full_size_invariants():
+@pytest.mark.parametrize("mapping", ["lane", "quad"])
+def test_full_size_invariants(mapping):
     """BASELINE config 2 size (4096 envs): properties that need no oracle."""
     import torch
     from quadruped_gym_amd.sim import BatchedSim
     n = 4096
     task = _abi.default_task()
     sim = BatchedSim(n, task=task)
+    sim.set_mapping(MAPPINGS[mapping])
     rng = np.random.default_rng(3)
     dev = torch.device("cuda:0")
     packed = torch.empty((n, 35), device=dev)
@@ -243,6 +256,7 @@ def test_full_size_invariants():
     assert (np.abs(act) <= np.array([0.5, 0.91, 1.0] * 4) + 1e-6).all()              # activations inside the ctrlrange
     # identical envs in different lanes / waves produce identical bits; different actions differ
     sim2 = BatchedSim(n, task=task)
+    sim2.set_mapping(MAPPINGS[mapping])
     same = torch.from_numpy(np.tile(rng.uniform(-1, 1, (1, 12)).astype(np.float32), (n, 1))).to(dev)
     for k in range(30):
         sim2.step_device_packed(same, packed)
@@ -254,7 +268,33 @@ def test_full_size_invariants():
     sim.close(); sim2.close()
 
 
-def test_sharding_does_not_change_results():
+def test_mappings_agree_with_each_other():
+    """The two mappings run the same arithmetic per leg; only the order of the four-leg sums differs,
+    so a 50-step rollout from reset stays within rounding-level drift of one another."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n = 256
+    sims = [BatchedSim(n), BatchedSim(n)]
+    sims[0].set_mapping(_abi.MAP_LANE)
+    sims[1].set_mapping(_abi.MAP_QUAD)
+    rng = np.random.default_rng(21)
+    for k in range(50):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        o0 = sims[0].step(a)
+        o1 = sims[1].step(a)
+        if k == 0:
+            assert np.allclose(o0[0], o1[0], atol=1e-4, rtol=1e-4)
+    q0, q1 = sims[0].get_state()[0], sims[1].get_state()[0]
+    assert np.allclose(q0, q1, atol=5e-3)
+    with pytest.raises(_abi.QuadGymError):
+        m = _abi.default_model()
+        m.body_mass[3] *= 1.1
+        BatchedSim(8, model=m).set_mapping(_abi.MAP_QUAD)      # quad mapping needs the compiled-in robot
+    for s in sims:
+        s.close()
+
+
+@pytest.mark.parametrize("mapping", ["lane", "quad"])
+def test_sharding_does_not_change_results(mapping):
     """Two handles of 128 envs with env_index_base 0 / 128 reproduce one handle of 256 bit for bit
     (per-env random streams are keyed by the global env index)."""
     from quadruped_gym_amd.sim import BatchedSim
@@ -266,6 +306,7 @@ def test_sharding_does_not_change_results():
     whole = BatchedSim(256, task=task)
     parts = [BatchedSim(128, task=task, env_index_base=0), BatchedSim(128, task=task, env_index_base=128)]
     for s in [whole] + parts:
+        s.set_mapping(MAPPINGS[mapping])
         s.reset(seed=9, flags=_abi.RESET_RANDOM_YAW)
     for k in range(12):
         a = rng.uniform(-1, 1, (256, 12)).astype(np.float32)
