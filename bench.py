@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--sync-gather", action="store_true", help="do not overlap the RCCL gather with the next step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
     import torch
@@ -144,6 +145,8 @@ def main():
     task.reset_flags = _abi.RESET_RANDOM_YAW if args.random_yaw else 0
     sim = BatchedSim(n, device=local_rank, task=task, env_index_base=rank * n)
     sim.set_track_ctrl(False)
+    sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD}[args.mapping])
+    mapping_name = {_abi.MAP_LANE: "one env per lane", _abi.MAP_QUAD: "one leg per lane (4 lanes per env)"}[sim.mapping]
     sim.reset(seed=0, flags=task.reset_flags)
     od = sim.obs_dim
     row = od + 2
@@ -197,6 +200,17 @@ def main():
     healthy = bool(np.isfinite(qpos).all())
 
     if rank == 0:
+        # HBM traffic per launch: committed rocprofv3 PMC measurement of this same configuration, when there is one
+        traffic, valu = None, None
+        try:
+            key = f"{'quad' if sim.mapping == _abi.MAP_QUAD else 'lane'}_n{n}_fs{args.frame_skip}_obs{od}"
+            with open(os.path.join(ROOT, "profiles", "traffic_index.json")) as fh:
+                ent = json.load(fh).get(key)
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                valu = ent.get("valu_insts_per_wave")
+        except Exception:
+            pass
         total_envs = n * world
         value = total_envs * args.steps / dt
         bytes_step = algorithmic_bytes_per_env_step(od)
@@ -210,15 +224,22 @@ def main():
                                    f"obs={od} f32, U(-1,1) actions resident in HBM"
                                    + (", random yaw at reset" if args.random_yaw else "")
                                    + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if world > 1 else ""),
-                       "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od},
+                       "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name},
             "substeps_per_sec": value * args.frame_skip,
             "state_finite": healthy,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "qg_step_kernel", "kernel_ms": kernel_ms,
+                         "traffic": traffic, "kernel": "qg_step_kernel_quad" if sim.mapping == _abi.MAP_QUAD else "qg_step_kernel",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_step * n,
                          "algorithmic_bytes_per_env_step": bytes_step,
-                         "note": "ALU/latency-bound path (no dense contraction): ~0.6 KB of state traffic per env-step "
-                                 "against tens of kflop; 4096 envs = 64 waves on 1024 SIMDs"},
+                         "note": "VALU-issue-bound path (no dense contraction): ~0.6 KB of state traffic per env-step against "
+                                 "~35 k VALU lane-instructions; the HBM fraction is small by construction"},
         }
+        if valu:
+            # issue-rate view of the same launch: wave-instructions/s against 1024 SIMDs x (2.4 GHz / 2 cycles per wave64 VALU op)
+            waves = -(-n // (16 if sim.mapping == _abi.MAP_QUAD else 64))
+            rate = valu * waves / (kernel_ms * 1e-3)
+            line["roofline"]["valu_issue"] = {"insts_per_wave": valu, "waves": waves, "achieved_ginst_s": rate / 1e9,
+                                              "peak_ginst_s": 1024 * 2.4 / 2, "frac": rate / (1024 * 1.2e9)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)
         print(json.dumps(line), flush=True)

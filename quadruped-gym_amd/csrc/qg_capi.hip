@@ -200,13 +200,13 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
     return QG_OK;
 }
 
-// One env per lane fills a wave per SIMD only from 65 536 envs up; below that the one-leg-per-lane
-// kernel (16 envs per wave, ~3.5x fewer instructions per wave) is faster.  It needs the baked robot.
-#define QG_QUAD_AUTO_MAX_ENVS 98304
+// The one-leg-per-lane kernel (16 envs per wave, ~3.5x fewer instructions per wave, no LDS scratch, lower
+// register pressure) measured faster than one env per lane at every batch size from 1 Ki to 256 Ki envs
+// (profiles/r01/sweep.txt), so AUTO picks it whenever the model is the compiled-in robot it needs.
 static int effective_mapping(const qg_sim *s) {
     if (!s->baked) return QG_MAP_LANE;
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
-    return s->n <= QG_QUAD_AUTO_MAX_ENVS ? QG_MAP_QUAD : QG_MAP_LANE;
+    return QG_MAP_QUAD;
 }
 
 static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_done, float *d_comps,
@@ -227,7 +227,10 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     if (effective_mapping(s) == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
-        hipLaunchKernelGGL(qg_step_kernel_quad, dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
+        if (qblocks <= 1024)      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
+            hipLaunchKernelGGL(qg_step_kernel_quad<1>, dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
+        else
+            hipLaunchKernelGGL(qg_step_kernel_quad<2>, dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
     } else if (s->baked)
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
     else

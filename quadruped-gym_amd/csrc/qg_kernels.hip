@@ -833,7 +833,10 @@ DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_s
 
 #define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
 
-__global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel_quad(const KTask *__restrict__ T, KStepArgs P) {
+// WPE = waves per SIMD the register allocation is capped for: 1 (all 512 registers) is fastest while the grid has at
+// most one wave per SIMD (n <= 16384); 2 lets a second wave share the SIMD once the grid is larger.
+template <int WPE>
+__global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask *__restrict__ T, KStepArgs P) {
     const KModel &C = QG_BAKED_MODEL;
     __shared__ float tile[QGK_QUAD_ENVS * 35];
     const int lane = threadIdx.x;
