@@ -104,6 +104,7 @@ typedef struct qg_task {
     int32_t use_time_limit;    /* use_default_termination, quadruped.py:52,99-100 */
     int32_t use_fall;          /* README.md:86-89 */
     double fall_height;        /* README literal 0.2; the base starts at 0.13 (quadruped.xml:62) */
+    int32_t use_flip;          /* walking_quad.py:156-166: body z axis (sensordata[29]) < 0 terminates */
     double w_forward;          /* reward = w_forward*qvel[0] + w_ctrl*sum(ctrl^2) + alive; README.md:65-72 */
     double w_ctrl;             /* -0.1 */
     double alive_bonus;        /* 1.0 */
@@ -179,6 +180,44 @@ int qg_uses_baked_model(const qg_sim *sim);
  * qg_get_mapping returns the mapping the next step will actually use (LANE or QUAD). */
 int qg_set_mapping(qg_sim *sim, int32_t mapping);
 int qg_get_mapping(const qg_sim *sim);
+
+/* ---- walking task layer ----------------------------------------------
+ * What WalkingQuadrupedEnv adds around QuadrupedEnv.step() (src/envs/walking_quad.py): the velocity /
+ * heading command (src/envs/control_inputs.py), the settling-time action mask (:142-143), the online
+ * frequency / amplitude estimator of the control signal (src/envs/math_utils.py:11-158), the 11-term
+ * reward of input_control_reward (:352-428) and the flip termination (:156-166).  A qg_walk is bound to
+ * one qg_sim (which must use the 33-value observation) and keeps the per-env task state on the device. */
+#define QG_NWALKREWARD 11   /* walking_quad.py:332-351 reward_keys */
+
+typedef struct qg_walk_params {
+    double settling_time;            /* walking_quad.py:11,142-143 */
+    double joint_centers[QG_NU];     /* :36-39  [0, 0, -0.5] * 4 */
+    double ema_alpha, min_freq;      /* :54-59  0.8, 1 Hz (window = ceil(2 / (min_freq * dt))) */
+    double control_cost_alpha;       /* :254    0.8 */
+    double w[10];                    /* :362-373 weights of the ten value terms, in reward_keys order */
+    double w_diff_ideal;             /* :383    -20 */
+    double body_height;              /* :369    0.13 */
+    double amp_target[QG_NU];        /* :279-285 [1.5, 0.5, 0] * 4 */
+    double freq_target[QG_NU];       /* :272-277 [1, 1, 0] * 4 */
+} qg_walk_params;
+
+typedef struct qg_walk qg_walk;
+
+int qg_walk_default_params(qg_walk_params *out);
+/* Binds the task layer to `sim` (switches its flip termination and data.ctrl tracking on). */
+int qg_walk_create(qg_sim *sim, const qg_walk_params *params, qg_walk **out);
+int qg_walk_destroy(qg_walk *walk);
+/* control_inputs.py: per-env local velocity (vx, vy) and heading unit vector (cos, sin); host pointers [n][2]. */
+int qg_walk_set_commands(qg_walk *walk, const float *velocity_xy, const float *heading_xy);
+/* WalkingQuadrupedEnv.reset (walking_quad.py:96-126): resets the robots (as qg_reset) and the per-episode task
+ * state; the estimator is NOT reset, as in the reference (:115). */
+int qg_walk_reset(qg_walk *walk, const uint8_t *mask, uint64_t seed, uint32_t flags);
+/* WalkingQuadrupedEnv.step (walking_quad.py:128-148).  components: [n][11] in reward_keys order, nullable. */
+int qg_walk_step(qg_walk *walk, const float *actions, float *obs, float *reward, uint8_t *done, float *components);
+int qg_walk_step_device(qg_walk *walk, const float *actions, float *obs, float *reward, uint8_t *done, float *components,
+                        void *stream);
+/* Snapshot of the estimator outputs (f_est, a_est: [n][12], host pointers) and the ideal position ([n][2]). */
+int qg_walk_get_estimates(qg_walk *walk, float *f_est, float *a_est, float *ideal_xy);
 
 #ifdef __cplusplus
 }

@@ -591,6 +591,7 @@ int qgo_step(const qg_model *m, const qg_task *t, qgo_env *e, const double *acti
     int d = 0;
     if (t->use_time_limit && e->nstep >= limit_substeps) d = 1;
     if (t->use_fall && e->qpos[2] < t->fall_height) d = 1;
+    if (t->use_flip && sens[29] < 0) d = 1;        /* walking_quad.py:156-160 */
     *done = d;
     return 0;
 }

@@ -60,6 +60,7 @@ class QgTask(C.Structure):
         ("use_time_limit", C.c_int32),
         ("use_fall", C.c_int32),
         ("fall_height", C.c_double),
+        ("use_flip", C.c_int32),
         ("w_forward", C.c_double),
         ("w_ctrl", C.c_double),
         ("alive_bonus", C.c_double),
@@ -69,6 +70,24 @@ class QgTask(C.Structure):
         ("reset_flags", C.c_uint32),
         ("default_ctrl", C.c_double * NU),
     ]
+
+
+class QgWalkParams(C.Structure):
+    _fields_ = [
+        ("settling_time", C.c_double),
+        ("joint_centers", C.c_double * NU),
+        ("ema_alpha", C.c_double),
+        ("min_freq", C.c_double),
+        ("control_cost_alpha", C.c_double),
+        ("w", C.c_double * 10),
+        ("w_diff_ideal", C.c_double),
+        ("body_height", C.c_double),
+        ("amp_target", C.c_double * NU),
+        ("freq_target", C.c_double * NU),
+    ]
+
+
+NWALKREWARD = 11
 
 
 def package_dir() -> str:
@@ -119,6 +138,14 @@ def load_library():
     lib.qg_uses_baked_model.argtypes = [vp]
     lib.qg_set_mapping.argtypes = [vp, C.c_int32]
     lib.qg_get_mapping.argtypes = [vp]
+    lib.qg_walk_default_params.argtypes = [C.POINTER(QgWalkParams)]
+    lib.qg_walk_create.argtypes = [vp, C.POINTER(QgWalkParams), C.POINTER(vp)]
+    lib.qg_walk_destroy.argtypes = [vp]
+    lib.qg_walk_set_commands.argtypes = [vp, vp, vp]
+    lib.qg_walk_reset.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+    lib.qg_walk_step.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.qg_walk_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.qg_walk_get_estimates.argtypes = [vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
@@ -132,6 +159,8 @@ EXPORTS = (
     "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
     "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
+    "qg_walk_default_params", "qg_walk_create", "qg_walk_destroy", "qg_walk_set_commands", "qg_walk_reset", "qg_walk_step",
+    "qg_walk_step_device", "qg_walk_get_estimates",
 )
 
 

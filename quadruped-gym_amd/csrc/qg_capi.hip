@@ -17,6 +17,7 @@
 #include "../../include/qg_model_data.h"
 // the kernels are compiled in the same translation unit (one code object, no -fgpu-rdc)
 #include "qg_kernels.hip"
+#include "qg_walk.hip"
 #include "qg_tables.h"
 
 struct qg_sim {
@@ -351,5 +352,201 @@ extern "C" int qg_uses_baked_model(const qg_sim *s) { return s ? s->baked : fail
 extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     s->track_ctrl = on ? 1 : 0;
+    return QG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// walking task layer (qg_walk.hip)
+// ------------------------------------------------------------------------------------------------------
+struct qg_walk {
+    qg_sim *sim;
+    qg_walk_params params;
+    KWalkParams kp;
+    KWalkState st;
+    float *d_obs, *d_reward, *d_comps, *d_actions, *d_tmp;
+    uint8_t *d_done;
+};
+
+extern "C" int qg_walk_default_params(qg_walk_params *p) {
+    if (!p) return fail(QG_ERR_ARG, "qg_walk_default_params: null output");
+    memset(p, 0, sizeof *p);
+    p->settling_time = 0.0;
+    for (int i = 0; i < QG_NU; i++) {
+        p->joint_centers[i] = (i % 3 == 2) ? -0.5 : 0.0;
+        p->amp_target[i] = (i % 3 == 0) ? 1.5 : ((i % 3 == 1) ? 0.5 : 0.0);
+        p->freq_target[i] = (i % 3 == 2) ? 0.0 : 1.0;
+    }
+    p->ema_alpha = 0.8;
+    p->min_freq = 1.0;
+    p->control_cost_alpha = 0.8;
+    const double w[10] = {10.0, -2.0, 10.0, -50.0, 10.0, 10.0, -50.0, -1.0, -2.5, -8.0};
+    for (int i = 0; i < 10; i++) p->w[i] = w[i];
+    p->w_diff_ideal = -20.0;
+    p->body_height = 0.13;
+    return QG_OK;
+}
+
+extern "C" int qg_walk_destroy(qg_walk *w) {
+    if (!w) return QG_OK;
+    (void)hipSetDevice(w->sim->device);
+    void *ptrs[] = {w->st.vel, w->st.head, w->st.gvel, w->st.ideal, w->st.prev_ctrl, w->st.prev_ctrl_cost, w->st.has_ctrl_cost,
+                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.cross, w->st.count, w->st.prev, w->st.sign,
+                    w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete w;
+    return QG_OK;
+}
+
+extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk **out) {
+    if (!s || !out) return fail(QG_ERR_ARG, "qg_walk_create: null argument");
+    *out = nullptr;
+    if (s->obs_dim != QG_NSENSOR) return fail(QG_ERR_ARG, "qg_walk_create: the walking rewards read the 33-value sensordata (obs_mode QG_OBS_FULL)");
+    qg_walk_params dp;
+    if (!params) { qg_walk_default_params(&dp); params = &dp; }
+    if (!(params->min_freq > 0) || !(params->ema_alpha >= 0 && params->ema_alpha <= 1)) return fail(QG_ERR_ARG, "qg_walk_create: bad estimator parameters");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    qg_walk *w = new (std::nothrow) qg_walk();
+    if (!w) return fail(QG_ERR_ALLOC, "out of host memory");
+    memset(w, 0, sizeof *w);
+    w->sim = s;
+    w->params = *params;
+    const double dt = s->model.timestep * s->task.frame_skip;        // walking_quad.py:56,93
+    KWalkParams &k = w->kp;
+    k.dt = (float)dt;
+    int64_t settle = params->settling_time > 0 ? qg_time_limit_substeps_impl(s->model.timestep, params->settling_time) : 0;
+    k.settle_substeps = (int32_t)(settle > INT32_MAX ? INT32_MAX : settle);
+    k.window = (int32_t)std::ceil(2.0 / (params->min_freq * dt));   // math_utils.py:26-28
+    k.ema_alpha = (float)params->ema_alpha;
+    k.control_cost_alpha = (float)params->control_cost_alpha;
+    for (int i = 0; i < 10; i++) k.w[i] = (float)params->w[i];
+    k.w_diff_ideal = (float)params->w_diff_ideal;
+    k.body_height = (float)params->body_height;
+    for (int i = 0; i < QG_NU; i++) {
+        k.joint_centers[i] = (float)params->joint_centers[i];
+        k.amp_target[i] = (float)params->amp_target[i];
+        k.freq_target[i] = (float)params->freq_target[i];
+    }
+    k.auto_reset = s->task.auto_reset;
+    const size_t n = (size_t)s->n, W = (size_t)k.window;
+#define WALLOC(ptr, bytes)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                \
+        if (e_ == hipSuccess) e_ = hipMemset((ptr), 0, (bytes));                            \
+        if (e_ != hipSuccess) {                                                             \
+            qg_walk_destroy(w);                                                             \
+            return fail(QG_ERR_ALLOC, "hipMalloc(%zu): %s", (size_t)(bytes), hipGetErrorString(e_)); \
+        }                                                                                   \
+    } while (0)
+    WALLOC(w->st.vel, 2 * n * 4); WALLOC(w->st.head, 2 * n * 4); WALLOC(w->st.gvel, 2 * n * 4); WALLOC(w->st.ideal, 2 * n * 4);
+    WALLOC(w->st.prev_ctrl, 12 * n * 4); WALLOC(w->st.prev_ctrl_cost, n * 4); WALLOC(w->st.has_ctrl_cost, n);
+    WALLOC(w->st.prev_derive, n * 4); WALLOC(w->st.has_derive, n); WALLOC(w->st.calls, n * 4);
+    WALLOC(w->st.sig, W * 12 * n * 4); WALLOC(w->st.cross, W * 12 * n); WALLOC(w->st.count, 12 * n * 4);
+    WALLOC(w->st.prev, 12 * n * 4); WALLOC(w->st.sign, 12 * n * 4); WALLOC(w->st.f_est, 12 * n * 4); WALLOC(w->st.a_est, 12 * n * 4);
+    WALLOC(w->st.eff_actions, 12 * n * 4);
+    WALLOC(w->d_obs, n * QG_NSENSOR * 4); WALLOC(w->d_reward, n * 4); WALLOC(w->d_comps, n * QG_NWALKREWARD * 4);
+    WALLOC(w->d_actions, n * 12 * 4); WALLOC(w->d_tmp, n * 12 * 4); WALLOC(w->d_done, n);
+#undef WALLOC
+    // the reference's termination set for this env: flip or time limit (walking_quad.py:162-166); data.ctrl feeds the estimator
+    s->task.use_flip = 1;
+    {
+        KModel km;
+        KTask kt;
+        int rc = build_tables(&s->model, &s->task, &km, &kt);
+        if (rc != QG_OK) { qg_walk_destroy(w); return rc; }
+        hipError_t e = hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { qg_walk_destroy(w); return fail(QG_ERR_DEVICE, "task update: %s", hipGetErrorString(e)); }
+    }
+    s->track_ctrl = 1;
+    *out = w;
+    int rc = qg_walk_reset(w, nullptr, 0, 0);
+    if (rc != QG_OK) { qg_walk_destroy(w); *out = nullptr; }
+    return rc;
+}
+
+extern "C" int qg_walk_set_commands(qg_walk *w, const float *velocity_xy, const float *heading_xy) {
+    if (!w || !velocity_xy || !heading_xy) return fail(QG_ERR_ARG, "qg_walk_set_commands: null argument");
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    size_t n = (size_t)s->n;
+    float *host = new (std::nothrow) float[6 * n];
+    if (!host) return fail(QG_ERR_ALLOC, "out of host memory");
+    float *vel = host, *head = host + 2 * n, *gv = host + 4 * n;
+    for (size_t i = 0; i < n; i++) {
+        float v0 = velocity_xy[2 * i], v1 = velocity_xy[2 * i + 1], h0 = heading_xy[2 * i], h1 = heading_xy[2 * i + 1];
+        vel[i] = v0; vel[n + i] = v1; head[i] = h0; head[n + i] = h1;
+        gv[i] = h0 * v0 - h1 * v1;                    // control_inputs.py:14-27
+        gv[n + i] = h1 * v0 + h0 * v1;
+    }
+    hipError_t e = hipMemcpy(w->st.vel, vel, 2 * n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(w->st.head, head, 2 * n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(w->st.gvel, gv, 2 * n * 4, hipMemcpyHostToDevice);
+    delete[] host;
+    if (e != hipSuccess) return fail(QG_ERR_DEVICE, "qg_walk_set_commands: %s", hipGetErrorString(e));
+    return QG_OK;
+}
+
+extern "C" int qg_walk_reset(qg_walk *w, const uint8_t *mask, uint64_t seed, uint32_t flags) {
+    if (!w) return fail(QG_ERR_ARG, "null handle");
+    qg_sim *s = w->sim;
+    int rc = qg_reset(s, mask, seed, flags);           // uploads the mask into s->d_mask
+    if (rc != QG_OK) return rc;
+    int threads = 256, blocks = (s->n + threads - 1) / threads;
+    hipLaunchKernelGGL(qg_walk_reset_kernel, dim3(blocks), dim3(threads), 0, s->stream, w->kp, w->st, s->n, mask ? s->d_mask : nullptr);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+extern "C" int qg_walk_step_device(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream) {
+    if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step_device: null argument");
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    hipStream_t st = (hipStream_t)stream;
+    int threads = 256;
+    int total = 12 * s->n;
+    hipLaunchKernelGGL(qg_walk_pre_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, w->kp, w->st, s->n, actions,
+                       (const float *)s->st.ctrl, (const int32_t *)s->st.nstep);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    int rc = launch_step(s, w->st.eff_actions, obs, reward, done, nullptr, nullptr, st);
+    if (rc != QG_OK) return rc;
+    hipLaunchKernelGGL(qg_walk_post_kernel, dim3((s->n + threads - 1) / threads), dim3(threads), 0, st, w->kp, w->st, s->n, (const float *)obs,
+                       (const uint8_t *)done, reward, components);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+extern "C" int qg_walk_step(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components) {
+    if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step: null argument");
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    size_t n = (size_t)s->n;
+    HIP_TRY(hipMemcpyAsync(w->d_actions, actions, n * 12 * 4, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
+    int rc = qg_walk_step_device(w, w->d_actions, w->d_obs, w->d_reward, w->d_done, components ? w->d_comps : nullptr, s->stream);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(obs, w->d_obs, n * QG_NSENSOR * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipMemcpyAsync(reward, w->d_reward, n * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipMemcpyAsync(done, w->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    if (components) HIP_TRY(hipMemcpyAsync(components, w->d_comps, n * QG_NWALKREWARD * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+extern "C" int qg_walk_get_estimates(qg_walk *w, float *f_est, float *a_est, float *ideal_xy) {
+    if (!w) return fail(QG_ERR_ARG, "null handle");
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    int threads = 256;
+    struct { const float *src; float *dst; int width; } jobs[3] = {{w->st.f_est, f_est, 12}, {w->st.a_est, a_est, 12}, {w->st.ideal, ideal_xy, 2}};
+    for (auto &j : jobs) {
+        if (!j.dst) continue;
+        int total = s->n * j.width;
+        hipLaunchKernelGGL(qg_transpose_out, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, j.src, w->d_tmp, s->n, j.width);
+        HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+        HIP_TRY(hipMemcpyAsync(j.dst, w->d_tmp, (size_t)total * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+        HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    }
     return QG_OK;
 }

@@ -42,6 +42,7 @@ struct KTask {
     int32_t limit_substeps;   // substep count at which data.time >= max_time (f64 accumulation), or INT32_MAX
     int32_t use_fall;
     float fall_height;
+    int32_t use_flip;         // body z axis of the (lagged) sensor pack below the horizon terminates
     float w_forward, w_ctrl, alive_bonus;
     int32_t obs_mode;         // 0: 33 sensors, 1: 21-value IMU pack
     int32_t sensor_lag;

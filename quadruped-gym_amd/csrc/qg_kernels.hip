@@ -680,6 +680,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
     float reward = c_fwd + c_ctl + c_alive;
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
+    if (T->use_flip) done = done || (so.zaxis.z < 0.f);          // walking_quad.py:156-160, on the step's sensordata
 
     // ---- outputs: stage rows in LDS, then store the wave's contiguous chunk coalesced ------
     const int od = T->obs_mode == 1 ? 21 : 33;
@@ -891,6 +892,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
     float reward = c_fwd + c_ctl + c_alive;
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
+    if (T->use_flip) done = done || (so.zaxis.z < 0.f);          // walking_quad.py:156-160, on the step's sensordata
 
     const int od = T->obs_mode == 1 ? 21 : 33;
     const int row = P.packed ? od + 2 : od;

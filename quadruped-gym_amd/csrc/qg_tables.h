@@ -117,6 +117,7 @@ static inline int build_tables(const qg_model *m, const qg_task *t, KModel *km, 
     kt->limit_substeps = (int32_t)(lim > INT32_MAX ? INT32_MAX : lim);
     kt->use_fall = t->use_fall;
     kt->fall_height = (float)t->fall_height;
+    kt->use_flip = t->use_flip;
     kt->w_forward = (float)t->w_forward;
     kt->w_ctrl = (float)t->w_ctrl;
     kt->alive_bonus = (float)t->alive_bonus;

@@ -1,0 +1,220 @@
+"""Walking task envs on the device task layer (``qg_walk_*`` in ``include/quadgym.h``): the batched
+counterpart of the reference's ``WalkingQuadrupedEnv`` (``src/envs/walking_quad.py``) -- velocity / heading
+command, settling-time action mask, control-signal frequency / amplitude estimator, the 11-term
+``input_control_reward`` and the flip + time-limit terminations -- for N robots per kernel launch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _abi
+from .._abi import NWALKREWARD, QgWalkParams, check
+from ..model.loader import load_model
+from ..sim import BatchedSim
+from .quadruped import ModelView
+from .spaces import Box
+
+REWARD_KEYS = ["alive_bonus", "control_cost", "progress_direction_reward_local", "progress_speed_cost_local",
+               "heading_reward", "orientation_reward", "body_height_cost", "joint_posture_cost",
+               "control_amplitude_cost", "control_frequency_cost", "diff_ideal_position_cost"]   # walking_quad.py:332-351
+
+
+def default_walk_params() -> QgWalkParams:
+    p = QgWalkParams()
+    check(_abi.load_library().qg_walk_default_params(C.byref(p)), "qg_walk_default_params")
+    return p
+
+
+def sample_command(options=None, uniform=None):
+    """``VelocityHeadingControls.sample`` (``src/envs/control_inputs.py:74-115``): returns
+    ``(velocity_xy, heading_xy)``; draws from ``np.random.uniform`` in the reference's order."""
+    uniform = uniform or np.random.uniform
+    options = options or {}
+    lo, hi = options.get("min_speed", 0.0), options.get("max_speed", 1.0)
+    th = options.get("fixed_heading_angle")
+    theta = th if th is not None else uniform(-np.pi, np.pi)
+    al = options.get("fixed_velocity_angle")
+    alpha = al if al is not None else uniform(-np.pi, np.pi)
+    sp = options.get("fixed_speed")
+    speed = sp if sp is not None else uniform(lo, hi)
+    return (speed * np.cos(alpha), speed * np.sin(alpha)), (np.cos(theta), np.sin(theta))
+
+
+class WalkingQuadrupedVecEnv:
+    """N walking robots; SB3 VecEnv calling convention (replaces ``SubprocVecEnv([make_env]*N)`` at
+    ``src/train_quadruped.py:50``).  ``infos[i]`` is the reward-component dict the reference returns as
+    ``info`` (``walking_quad.py:146-148,419``), which ``RewardCallback`` reads (``train_quadruped.py:86-97``)."""
+
+    reward_keys = REWARD_KEYS
+
+    def __init__(self, num_envs, settling_time=0, random_controls=False, random_init=False, reset_options=None,
+                 model_path="builtin", max_time=10.0, frame_skip=4, device=0, env_index_base=0, seed=0, walk_params=None):
+        qg_model, layout = load_model(model_path)
+        self.model = ModelView(qg_model, layout)
+        self.num_envs = int(num_envs)
+        self.frame_skip, self.max_time = int(frame_skip), float(max_time)
+        self.random_controls, self.random_init, self.reset_options = random_controls, random_init, reset_options
+        task = _abi.default_task()
+        task.frame_skip = self.frame_skip
+        task.max_time = self.max_time
+        task.use_time_limit = 1
+        task.use_fall = 0
+        task.use_flip = 1                                   # walking_quad.py:156-166
+        task.auto_reset = 1
+        task.reset_flags = _abi.RESET_RANDOM_YAW if random_init else 0     # walking_quad.py:68-75,118-119
+        self._sim = BatchedSim(self.num_envs, device=device, model=qg_model, task=task, env_index_base=env_index_base)
+        self._lib = _abi.load_library()
+        self.params = walk_params if walk_params is not None else default_walk_params()
+        self.params.settling_time = float(settling_time)
+        h = C.c_void_p()
+        check(self._lib.qg_walk_create(self._sim._h, C.byref(self.params), C.byref(h)), "qg_walk_create")
+        self._w = h
+        self._seed = int(seed)
+        self._flags = task.reset_flags
+        self.action_space = Box(low=-1.0, high=1.0, shape=(12,), dtype=np.float32)
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(33,), dtype=np.float32)
+        self.velocity = np.zeros((self.num_envs, 2), np.float32)
+        self.heading = np.zeros((self.num_envs, 2), np.float32)
+        self.dt = qg_model.timestep * self.frame_skip
+        self.render_mode = None
+
+    # -- commands ---------------------------------------------------------------------------------
+    def set_commands(self, velocity_xy, heading_xy):
+        self.velocity[:] = np.asarray(velocity_xy, np.float32).reshape(self.num_envs, 2)
+        self.heading[:] = np.asarray(heading_xy, np.float32).reshape(self.num_envs, 2)
+        check(self._lib.qg_walk_set_commands(self._w, self.velocity.ctypes.data, self.heading.ctypes.data), "qg_walk_set_commands")
+
+    def _resample(self, idx):
+        for i in idx:
+            v, hd = sample_command(self.reset_options)
+            self.velocity[i], self.heading[i] = v, hd
+        check(self._lib.qg_walk_set_commands(self._w, self.velocity.ctypes.data, self.heading.ctypes.data), "qg_walk_set_commands")
+
+    # -- VecEnv protocol ------------------------------------------------------------------------------
+    def reset(self):
+        check(self._lib.qg_walk_reset(self._w, None, self._seed, self._flags), "qg_walk_reset")
+        if self.random_controls:                              # walking_quad.py:121-122
+            self._resample(range(self.num_envs))
+        return np.zeros((self.num_envs, 33), np.float32)
+
+    def step_async(self, actions):
+        self._actions = np.ascontiguousarray(actions, dtype=np.float32)
+
+    def step_wait(self):
+        n = self.num_envs
+        a = self._actions
+        if a.shape != (n, 12):
+            raise ValueError(f"actions must have shape ({n}, 12)")
+        obs = np.empty((n, 33), np.float32)
+        rew = np.empty(n, np.float32)
+        done = np.empty(n, np.uint8)
+        comps = np.empty((n, NWALKREWARD), np.float32)
+        check(self._lib.qg_walk_step(self._w, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, comps.ctypes.data),
+              "qg_walk_step")
+        dones = done.astype(bool)
+        infos = []
+        for i in range(n):
+            info = {k: float(comps[i, j]) for j, k in enumerate(REWARD_KEYS)}
+            if dones[i]:
+                info["terminal_observation"] = obs[i].copy()
+                info["TimeLimit.truncated"] = False
+            infos.append(info)
+        if dones.any():
+            obs = obs.copy()
+            obs[dones] = 0.0
+            if self.random_controls:
+                self._resample(np.nonzero(dones)[0])
+        self.last_components = comps
+        return obs, rew, dones, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def estimates(self):
+        f = np.empty((self.num_envs, 12), np.float32)
+        a = np.empty((self.num_envs, 12), np.float32)
+        ideal = np.empty((self.num_envs, 2), np.float32)
+        check(self._lib.qg_walk_get_estimates(self._w, f.ctypes.data, a.ctypes.data, ideal.ctypes.data), "qg_walk_get_estimates")
+        return f, a, ideal
+
+    def step_tensor(self, actions, obs, reward, done, components=None, stream=None):
+        """Zero-copy step on CUDA tensors (float32 ``[N,12]``, ``[N,33]``, ``[N]``, uint8 ``[N]``, ``[N,11]``)."""
+        check(self._lib.qg_walk_step_device(self._w, actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                                            components.data_ptr() if components is not None else None,
+                                            self._sim._stream_ptr(stream)), "qg_walk_step_device")
+
+    def close(self):
+        if getattr(self, "_w", None):
+            self._lib.qg_walk_destroy(self._w)
+            self._w = None
+        if getattr(self, "_sim", None) is not None:
+            self._sim.close()
+            self._sim = None
+
+    def seed(self, seed=None):
+        self._seed = 0 if seed is None else int(seed)
+        return [self._seed + i for i in range(self.num_envs)]
+
+    def get_attr(self, attr_name, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [getattr(self, attr_name) for _ in idx]
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [getattr(self, method_name)(*args, **kwargs) for _ in idx]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
+        return [False for _ in idx]
+
+
+class WalkingQuadrupedEnv:
+    """One walking robot with the reference's constructor (``walking_quad.py:11``): ``settling_time``,
+    ``random_controls``, ``random_init``, ``reset_options`` plus the base env's keyword arguments;
+    ``step`` returns ``(obs, reward, terminated, False, info)`` with ``info`` = the component dict."""
+
+    reward_keys = REWARD_KEYS
+
+    def __init__(self, settling_time=0, random_controls=False, random_init=False, reset_options=None, **kwargs):
+        allowed = {"model_path", "max_time", "frame_skip", "device"}
+        ignored = {"render_mode", "width", "height", "render_fps", "save_video", "video_path", "use_default_termination",
+                   "reward_fns", "termination_fns"}
+        extra = set(kwargs) - allowed - ignored
+        if extra:
+            raise TypeError(f"unexpected keyword arguments {sorted(extra)}")
+        if kwargs.get("render_mode") is not None or kwargs.get("save_video"):
+            raise NotImplementedError("rendering / video recording is not part of the HIP path")
+        args = {k: v for k, v in kwargs.items() if k in allowed}
+        args.setdefault("model_path", "./models/quadruped/scene.xml")      # quadruped.py:41
+        self._vec = WalkingQuadrupedVecEnv(1, settling_time, random_controls, random_init, reset_options, **args)
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.model = self._vec.model
+        self.info = {}
+
+    def reset(self, seed=None, options=None):
+        if options is not None:
+            self._vec.reset_options = options                  # walking_quad.py:100-101
+        obs = self._vec.reset()
+        self.info = {}
+        return obs[0].astype(np.float64), self.info
+
+    def step(self, action):
+        obs, rew, dones, infos = self._vec.step(np.asarray(action, np.float32)[None])
+        info = dict(infos[0])
+        term_obs = info.pop("terminal_observation", None)
+        info.pop("TimeLimit.truncated", None)
+        self.info = info
+        out = term_obs if term_obs is not None else obs[0]     # a single env is not auto-continued: hand back the last obs
+        return out.astype(np.float64), float(rew[0]), bool(dones[0]), False, self.info
+
+    def set_command(self, velocity_xy, heading_xy):
+        self._vec.set_commands([velocity_xy], [heading_xy])
+
+    def close(self):
+        self._vec.close()

@@ -1,0 +1,110 @@
+"""The device walking task layer (qg_walk_*) against the walking oracle, which is itself pinned to the
+reference's estimator / command code by tests/test_walking_oracle.py.  The oracle is fed the GPU's own
+observations, so the comparison isolates the task layer from the (chaotic) physics rollout."""
+import numpy as np
+import pytest
+
+from oracle import walking_oracle as W
+from quadruped_gym_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("frame_skip", [4, 20])
+def test_walking_rewards_match_oracle(frame_skip):
+    from quadruped_gym_amd.envs.walking import REWARD_KEYS, WalkingQuadrupedVecEnv
+    n = 70
+    settle = 0.05
+    env = WalkingQuadrupedVecEnv(n, settling_time=settle, frame_skip=frame_skip, max_time=1000.0)
+    assert REWARD_KEYS == W.REWARD_KEYS
+    dt = 0.002 * frame_skip
+    o = W.WalkingOracle(n, dt, settling_time=settle)
+    rng = np.random.default_rng(3)
+    sp, al, th = rng.uniform(0.1, 0.5, n), rng.uniform(-np.pi, np.pi, n), rng.uniform(-np.pi, np.pi, n)
+    for i in range(n):
+        o.controls.set_orientation(i, th[i])
+        o.controls.set_velocity_speed_alpha(i, sp[i], al[i])
+    env.set_commands(o.controls.velocity[:, :2], o.controls.heading[:, :2])
+    env.reset()
+    o.reset()
+    steps = 2 * o.est.W + 30                       # let the estimator's ring buffer wrap
+    t = 0.0
+    data_ctrl = np.tile([0, 0, -0.5] * 4, (n, 1)).astype(np.float64)       # quadruped.py:124
+    ph = rng.uniform(0, 2 * np.pi, (n, 12)); fr = rng.uniform(0.5, 4.0, (n, 12)); am = rng.uniform(0.1, 1.2, (n, 12))
+    saw_nan = False
+    for k in range(steps):
+        a = (am * np.sin(2 * np.pi * fr * k * dt + ph) + 0.05 * rng.normal(size=(n, 12))).astype(np.float32)
+        if k % 7 == 0:
+            a[:, 3] = a[:, 3]                       # keep a channel exactly repeating its previous value sometimes
+        obs, rew, dones, infos = env.step(a)
+        assert not dones.any()
+        act = o.pre_step(np.full(n, t), data_ctrl, a.astype(np.float64))
+        ctrl = np.clip(act, -1, 1)
+        tot, comps, flip = o.post_step(obs.astype(np.float64), ctrl)
+        got = env.last_components.astype(np.float64)
+        # f32 kernel vs f64 oracle on identical inputs; the derived term divides a difference of f32 sensors by dt
+        # (unit() of an exactly zero local velocity -- the vertical drop of the first steps -- is NaN in the reference too)
+        assert np.allclose(got[:, :10], comps[:, :10], rtol=2e-4, atol=2e-4, equal_nan=True), (k, np.nanmax(np.abs(got[:, :10] - comps[:, :10])))
+        assert np.allclose(got[:, 10], comps[:, 10], rtol=1e-3, atol=2e-2 / dt * 1e-3 + 1e-3), k
+        assert np.allclose(rew, got.sum(1), rtol=1e-5, atol=1e-4, equal_nan=True)
+        saw_nan = saw_nan or bool(np.isnan(got).any())
+        for i in (0, n - 1):
+            assert infos[i][REWARD_KEYS[3]] == pytest.approx(got[i, 3], nan_ok=True)
+        data_ctrl = ctrl
+        for _ in range(frame_skip):
+            t += 0.002
+    f, amp, ideal = env.estimates()
+    assert np.allclose(f, o.f_est, rtol=1e-4, atol=1e-4) and np.allclose(amp, o.a_est, rtol=1e-4, atol=1e-5)
+    assert np.allclose(ideal, o.ideal[:, :2], rtol=1e-4, atol=1e-5)
+    assert (f > 0.2).any() and (amp > 0.2).any()
+    env.close()
+
+
+def test_settling_mask_flip_and_auto_reset():
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    n = 40
+    env = WalkingQuadrupedVecEnv(n, settling_time=0.1, max_time=0.3, random_init=True, random_controls=True,
+                                 reset_options={"fixed_heading_angle": 0.0, "fixed_velocity_angle": 0.0, "fixed_speed": 0.3})
+    env.reset()
+    assert np.allclose(env.velocity, [0.3, 0.0]) and np.allclose(env.heading, [1.0, 0.0])    # train_quadruped.py:40-46
+    a = np.ones((n, 12), np.float32)
+    env.step(a)
+    ctrl = env._sim.get_state()[3]
+    assert np.allclose(ctrl, [0, 0, -0.5] * 4)             # data.time < settling_time: joint centres applied
+    k_done = None
+    for k in range(2, 60):
+        obs, rew, dones, infos = env.step(a)
+        if dones.all():
+            k_done = k
+            break
+    assert k_done == 38                                    # 0.3 s -> 151 substeps (f64 clock) -> 38 env-steps of 4
+    assert "terminal_observation" in infos[0] and not obs.any()
+    ctrl = env._sim.get_state()[3]
+    assert np.allclose(ctrl, [0, 0, -0.5] * 4)             # auto-reset restored the default ctrl
+    # flip termination: put one robot on its back
+    env2 = WalkingQuadrupedVecEnv(8, max_time=100.0)
+    env2.reset()
+    qpos = env2._sim.get_state()[0]
+    qpos[3, 2] = 0.3
+    qpos[3, 3:7] = [0, 1, 0, 0]                             # rolled by 180 degrees
+    env2._sim.set_state(qpos=qpos)
+    obs, rew, dones, infos = env2.step(np.zeros((8, 12), np.float32))
+    assert dones[3] and not dones[[0, 1, 2, 4, 5, 6, 7]].any()
+    env.close(); env2.close()
+
+
+def test_single_env_facade_has_reference_signature():
+    import inspect
+    from quadruped_gym_amd.envs.walking import REWARD_KEYS, WalkingQuadrupedEnv
+    sig = list(inspect.signature(WalkingQuadrupedEnv.__init__).parameters)
+    assert sig[:5] == ["self", "settling_time", "random_controls", "random_init", "reset_options"]   # walking_quad.py:11
+    env = WalkingQuadrupedEnv(settling_time=0.0, random_controls=True, reset_options={"fixed_heading_angle": 0.0,
+                              "fixed_velocity_angle": 0.0, "fixed_speed": 0.3}, model_path="builtin", max_time=20.0, frame_skip=10)
+    obs, info = env.reset()
+    assert obs.shape == (33,) and info == {}
+    rng = np.random.default_rng(0)
+    for _ in range(5):      # the symmetric drop of the first steps has exactly zero local xy velocity: unit() -> NaN, as math_utils.unit
+        obs, r, term, trunc, info = env.step(rng.uniform(-1, 1, 12).astype(np.float32))
+    assert set(info) == set(REWARD_KEYS) and trunc is False and isinstance(r, float)
+    assert np.isfinite(r) and r == pytest.approx(sum(info.values()), rel=1e-5)
+    env.close()
