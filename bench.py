@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--sync-gather", action="store_true", help="do not overlap the RCCL gather with the next step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--walking", action="store_true", help="time the walking task layer too (SURVEY 8 f1): pre + physics + post kernels per env-step")
     ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
@@ -161,11 +162,28 @@ def main():
         from quadruped_gym_amd.dist import PackedGatherer
         gatherer = PackedGatherer(n, row, dev, dst=0)
 
+    walk = None
+    if args.walking:
+        import ctypes as C
+        from quadruped_gym_amd._abi import check
+        lib = _abi.load_library()
+        walk = C.c_void_p()
+        check(lib.qg_walk_create(sim._h, None, C.byref(walk)), "qg_walk_create")
+        cmd_v = np.tile(np.array([[0.3, 0.0]], np.float32), (n, 1))
+        cmd_h = np.tile(np.array([[1.0, 0.0]], np.float32), (n, 1))
+        check(lib.qg_walk_set_commands(walk, cmd_v.ctypes.data, cmd_h.ctypes.data), "qg_walk_set_commands")
+        w_obs = torch.empty((n, 33), device=dev); w_rew = torch.empty(n, device=dev)
+        w_done = torch.empty(n, device=dev, dtype=torch.uint8); w_comp = torch.empty((n, 11), device=dev)
+
     def run(k0, count):
         for k in range(k0, k0 + count):
             b = k & 1
             if gatherer is not None:
                 gatherer.wait_buffer_free(compute)       # the gather that read packed[b] two steps ago
+            if walk is not None:
+                check(lib.qg_walk_step_device(walk, pool[k & 15].data_ptr(), w_obs.data_ptr(), w_rew.data_ptr(), w_done.data_ptr(),
+                                              w_comp.data_ptr(), C.c_void_p(compute.cuda_stream)), "qg_walk_step_device")
+                continue
             sim.step_device_packed(pool[k & 15], packed[b], stream=compute)
             if gatherer is not None:
                 gatherer.submit(packed[b])               # RCCL gather on the communication stream
@@ -223,6 +241,7 @@ def main():
                                    f"forward+control_cost+alive rewards, fall(z<0.05)+time-limit terminations, auto-reset, "
                                    f"obs={od} f32, U(-1,1) actions resident in HBM"
                                    + (", random yaw at reset" if args.random_yaw else "")
+                                   + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
                                    + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if world > 1 else ""),
                        "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name},
             "substeps_per_sec": value * args.frame_skip,

@@ -390,7 +390,7 @@ extern "C" int qg_walk_destroy(qg_walk *w) {
     if (!w) return QG_OK;
     (void)hipSetDevice(w->sim->device);
     void *ptrs[] = {w->st.vel, w->st.head, w->st.gvel, w->st.ideal, w->st.prev_ctrl, w->st.prev_ctrl_cost, w->st.has_ctrl_cost,
-                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.cross, w->st.count, w->st.prev, w->st.sign,
+                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.cross, w->st.count, w->st.prev, w->st.sign,
                     w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -441,7 +441,11 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     WALLOC(w->st.vel, 2 * n * 4); WALLOC(w->st.head, 2 * n * 4); WALLOC(w->st.gvel, 2 * n * 4); WALLOC(w->st.ideal, 2 * n * 4);
     WALLOC(w->st.prev_ctrl, 12 * n * 4); WALLOC(w->st.prev_ctrl_cost, n * 4); WALLOC(w->st.has_ctrl_cost, n);
     WALLOC(w->st.prev_derive, n * 4); WALLOC(w->st.has_derive, n); WALLOC(w->st.calls, n * 4);
-    WALLOC(w->st.sig, W * 12 * n * 4); WALLOC(w->st.cross, W * 12 * n); WALLOC(w->st.count, 12 * n * 4);
+    WALLOC(w->st.sig, W * 12 * n * 4); WALLOC(w->st.cross, W * 12 * n);
+    {
+        size_t nb = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
+        WALLOC(w->st.bmax, nb * 12 * n * 4); WALLOC(w->st.bmin, nb * 12 * n * 4);
+    } WALLOC(w->st.count, 12 * n * 4);
     WALLOC(w->st.prev, 12 * n * 4); WALLOC(w->st.sign, 12 * n * 4); WALLOC(w->st.f_est, 12 * n * 4); WALLOC(w->st.a_est, 12 * n * 4);
     WALLOC(w->st.eff_actions, 12 * n * 4);
     WALLOC(w->d_obs, n * QG_NSENSOR * 4); WALLOC(w->d_reward, n * 4); WALLOC(w->d_comps, n * QG_NWALKREWARD * 4);

@@ -13,10 +13,15 @@
 //   qg_walk_post_kernel  one thread per env: the 11 reward terms of input_control_reward (:352-428) on the step's
 //                        sensordata and data.ctrl, their sum, episode bookkeeping of envs that finished.
 // The estimator's amplitude is max - min over a sliding window of 2 / (min_freq * dt) samples (250 at frame_skip
-// 4): the pre kernel streams window x 12 x n floats per env-step (12 KB per env), laid out [w][channel][env] so
-// that consecutive threads touch consecutive addresses -- this kernel, unlike the physics, is bandwidth-bound.
+// 4).  Scanning the window every step streams 12 KB per env (measured 62.7 us per launch at 4096 envs, 3x the
+// physics), so the ring buffer carries per-block (16 samples) max / min summaries: a step re-reduces the one block
+// that received the new sample and combines it with the other blocks' summaries -- 16 + 2*15 values instead of
+// 250, bit-identical results (max / min are exact).  Buffers are laid out [slot][channel][env] so that consecutive
+// threads touch consecutive addresses.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#define QG_WALK_BLOCK 16      // samples per block summary of the estimator's ring buffer
 
 struct KWalkParams {
     float dt;                    // timestep * frame_skip
@@ -45,6 +50,7 @@ struct KWalkState {
     // estimator (math_utils.py): never reset between episodes (walking_quad.py:115)
     int32_t *calls;          // [n]      update() calls so far: buffer index = calls % window, samples = min(calls, window)
     float *sig;              // [window][12][n]
+    float *bmax, *bmin;      // [blocks][12][n]  max / min of each 16-sample block of the ring buffer
     uint8_t *cross;          // [window][12][n]
     int32_t *count;          // [12][n]  running number of derivative sign changes inside the window
     float *prev;             // [12][n]
@@ -73,6 +79,8 @@ __global__ void qg_walk_pre_kernel(KWalkParams P, KWalkState S, int n, const flo
     if (calls == 0) {                                   // first call: remember the sample, estimates stay 0 (:66-72)
         S.prev[t] = x;
         S.sig[slot] = x;
+        S.bmax[t] = x;                                  // block 0 holds exactly this sample
+        S.bmin[t] = x;
         return;
     }
     float d = x - S.prev[t];
@@ -93,15 +101,31 @@ __global__ void qg_walk_pre_kernel(KWalkParams P, KWalkState S, int n, const flo
     const float dur = (float)samples * P.dt;            // :109
     const float f_cur = (0.5f * (float)cnt) / dur;      // :113-114
     S.f_est[t] = P.ema_alpha * S.f_est[t] + (1.f - P.ema_alpha) * f_cur;           // :117
-    // amplitude = max - min over the filled part of the window (:121-126); the new sample is in registers
-    float mx = x, mn = x;
-    const float *col = S.sig + t;
+    // amplitude = max - min over the filled part of the window (:121-126), through the block summaries
     const size_t stride = (size_t)12 * n;
-    for (int w = 0; w < samples; ++w) {
-        if (w == idx) continue;
-        float v = col[(size_t)w * stride];
-        mx = fmaxf(mx, v);
-        mn = fminf(mn, v);
+    const int bidx = idx / QG_WALK_BLOCK;
+    const int nblocks = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
+    float mx = x, mn = x;
+    {
+        const float *col = S.sig + t + (size_t)bidx * QG_WALK_BLOCK * stride;
+        const int base = bidx * QG_WALK_BLOCK;
+#pragma unroll
+        for (int j = 0; j < QG_WALK_BLOCK; ++j) {
+            const int slot_j = base + j;
+            if (slot_j < samples && slot_j != idx) {        // filled slots only (samples == W once the buffer has wrapped)
+                float v = col[(size_t)j * stride];
+                mx = fmaxf(mx, v);
+                mn = fminf(mn, v);
+            }
+        }
+        S.bmax[(size_t)bidx * stride + t] = mx;
+        S.bmin[(size_t)bidx * stride + t] = mn;
+    }
+    for (int b = 0; b < nblocks; ++b) {
+        if (b != bidx && b * QG_WALK_BLOCK < samples) {      // blocks that hold at least one filled slot
+            mx = fmaxf(mx, S.bmax[(size_t)b * stride + t]);
+            mn = fminf(mn, S.bmin[(size_t)b * stride + t]);
+        }
     }
     S.a_est[t] = P.ema_alpha * S.a_est[t] + (1.f - P.ema_alpha) * (mx - mn);       // :129
 }
