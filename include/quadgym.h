@@ -219,6 +219,25 @@ int qg_walk_step_device(qg_walk *walk, const float *actions, float *obs, float *
 /* Snapshot of the estimator outputs (f_est, a_est: [n][12], host pointers) and the ideal position ([n][2]). */
 int qg_walk_get_estimates(qg_walk *walk, float *f_est, float *a_est, float *ideal_xy);
 
+/* ---- partially observable observation pack ---------------------------------
+ * POWalkingQuadrupedEnv (src/envs/po_walking_quad.py:10-90): per step one 26-value frame [gyro 3, accel 3,
+ * Madgwick-IMU Euler angles 3, body_vel xy 2, data.ctrl 12, command vx vy theta 3], stacked over obs_window
+ * steps (FIFO).  Sits on top of a qg_walk. */
+#define QG_PO_FRAME_DIM 26
+
+typedef struct qg_po qg_po;
+
+int qg_po_create(qg_walk *walk, int32_t obs_window, qg_po **out);          /* po_walking_quad.py:10-27 */
+int qg_po_destroy(qg_po *po);
+int qg_po_obs_dim(const qg_po *po);                                         /* 26 * obs_window */
+/* POWalkingQuadrupedEnv.reset (:59-69); obs (nullable, host pointer [n][obs_dim]) receives the stacked reset frames */
+int qg_po_reset(qg_po *po, const uint8_t *mask, uint64_t seed, uint32_t flags, float *obs);
+/* POWalkingQuadrupedEnv.step (:72-90).  obs: [n][obs_dim]; terminal_obs: nullable, receives the last stacked
+ * observation of envs that finished (rows of other envs are left untouched); components: [n][11], nullable. */
+int qg_po_step(qg_po *po, const float *actions, float *obs, float *reward, uint8_t *done, float *components, float *terminal_obs);
+int qg_po_step_device(qg_po *po, const float *actions, float *obs, float *reward, uint8_t *done, float *components,
+                      float *terminal_obs, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,12 @@ def load_library():
     lib.qg_walk_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qg_walk_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.qg_walk_get_estimates.argtypes = [vp, vp, vp, vp]
+    lib.qg_po_create.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    lib.qg_po_destroy.argtypes = [vp]
+    lib.qg_po_obs_dim.argtypes = [vp]
+    lib.qg_po_reset.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
+    lib.qg_po_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.qg_po_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
@@ -161,6 +167,7 @@ EXPORTS = (
     "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
     "qg_walk_default_params", "qg_walk_create", "qg_walk_destroy", "qg_walk_set_commands", "qg_walk_reset", "qg_walk_step",
     "qg_walk_step_device", "qg_walk_get_estimates",
+    "qg_po_create", "qg_po_destroy", "qg_po_obs_dim", "qg_po_reset", "qg_po_step", "qg_po_step_device",
 )
 
 

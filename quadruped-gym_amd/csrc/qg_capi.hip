@@ -18,6 +18,7 @@
 // the kernels are compiled in the same translation unit (one code object, no -fgpu-rdc)
 #include "qg_kernels.hip"
 #include "qg_walk.hip"
+#include "qg_po.hip"
 #include "qg_tables.h"
 
 struct qg_sim {
@@ -552,5 +553,132 @@ extern "C" int qg_walk_get_estimates(qg_walk *w, float *f_est, float *a_est, flo
         HIP_TRY(hipMemcpyAsync(j.dst, w->d_tmp, (size_t)total * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
         HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
     }
+    return QG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// partially observable observation pack (qg_po.hip)
+// ------------------------------------------------------------------------------------------------------
+struct qg_po {
+    qg_walk *walk;
+    KPoParams kp;
+    KPoState st;
+    float *d_obs33, *d_out, *d_term;
+};
+
+extern "C" int qg_po_destroy(qg_po *p) {
+    if (!p) return QG_OK;
+    (void)hipSetDevice(p->walk->sim->device);
+    void *ptrs[] = {p->st.orient, p->st.alias, p->st.nstep, p->st.stack, p->d_obs33, p->d_out, p->d_term};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+    return QG_OK;
+}
+
+extern "C" int qg_po_obs_dim(const qg_po *p) { return p ? p->kp.window * QG_PO_FRAME : fail(QG_ERR_ARG, "null handle"); }
+
+static int po_reset_kernel(qg_po *p, const uint8_t *dmask, float *d_out) {
+    qg_sim *s = p->walk->sim;
+    int threads = 256, blocks = (s->n + threads - 1) / threads;
+    hipLaunchKernelGGL(qg_po_reset_kernel, dim3(blocks), dim3(threads), 0, s->stream, p->kp, p->st, s->n, dmask, (const float *)p->walk->st.vel,
+                       (const float *)p->walk->st.head, d_out);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+extern "C" int qg_po_create(qg_walk *w, int32_t obs_window, qg_po **out) {
+    if (!w || !out) return fail(QG_ERR_ARG, "qg_po_create: null argument");
+    *out = nullptr;
+    if (obs_window < 1 || obs_window > 64) return fail(QG_ERR_ARG, "qg_po_create: obs_window must be in 1..64");
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    qg_po *p = new (std::nothrow) qg_po();
+    if (!p) return fail(QG_ERR_ALLOC, "out of host memory");
+    memset(p, 0, sizeof *p);
+    p->walk = w;
+    KPoParams &k = p->kp;
+    k.dt = (float)(s->model.timestep * s->task.frame_skip);          // po_walking_quad.py:18
+    k.gain = 0.033f;                                                  // the library's default IMU gain
+    // data.time > settling_time / 2 (:37): first substep count whose f64-accumulated clock exceeds it
+    {
+        double t = 0, half = w->params.settling_time / 2;
+        int64_t c = 0;
+        while (!(t > half) && c < INT32_MAX) { t += s->model.timestep; c++; }
+        k.half_settle_substeps = (int32_t)c;
+    }
+    k.window = obs_window;
+    k.frame_skip = s->task.frame_skip;
+    k.auto_reset = s->task.auto_reset;
+    for (int i = 0; i < QG_NU; i++) k.default_ctrl[i] = (float)s->task.default_ctrl[i];
+    size_t n = (size_t)s->n, width = (size_t)obs_window * QG_PO_FRAME;
+    hipError_t e = hipMalloc((void **)&p->st.orient, 4 * n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->st.alias, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->st.nstep, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->st.stack, n * width * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_obs33, n * QG_NSENSOR * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_out, n * width * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_term, n * width * 4);
+    if (e == hipSuccess) e = hipMemset(p->st.alias, 0, n);
+    if (e == hipSuccess) e = hipMemset(p->st.nstep, 0, n * 4);
+    if (e == hipSuccess) e = hipMemset(p->st.stack, 0, n * width * 4);
+    if (e == hipSuccess) {                                           // computed_orientation = [1, 0, 0, 0] (:19)
+        float *h = new float[4 * n];
+        for (size_t i = 0; i < n; i++) { h[i] = 1.f; h[n + i] = h[2 * n + i] = h[3 * n + i] = 0.f; }
+        e = hipMemcpy(p->st.orient, h, 4 * n * 4, hipMemcpyHostToDevice);
+        delete[] h;
+    }
+    if (e != hipSuccess) {
+        qg_po_destroy(p);
+        return fail(QG_ERR_ALLOC, "qg_po_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return QG_OK;
+}
+
+extern "C" int qg_po_reset(qg_po *p, const uint8_t *mask, uint64_t seed, uint32_t flags, float *obs) {
+    if (!p) return fail(QG_ERR_ARG, "null handle");
+    qg_sim *s = p->walk->sim;
+    // the reset frame shows the estimate and the command as they stand BEFORE the robots / commands are reset (:59-69)
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    if (mask) HIP_TRY(hipMemcpy(s->d_mask, mask, (size_t)s->n, hipMemcpyHostToDevice), QG_ERR_DEVICE);
+    int rc = po_reset_kernel(p, mask ? s->d_mask : nullptr, p->d_out);
+    if (rc != QG_OK) return rc;
+    if (obs) HIP_TRY(hipMemcpy(obs, p->d_out, (size_t)s->n * p->kp.window * QG_PO_FRAME * 4, hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    return qg_walk_reset(p->walk, mask, seed, flags);
+}
+
+extern "C" int qg_po_step_device(qg_po *p, const float *actions, float *obs, float *reward, uint8_t *done, float *components,
+                                 float *terminal_obs, void *stream) {
+    if (!p || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_po_step_device: null argument");
+    qg_walk *w = p->walk;
+    qg_sim *s = w->sim;
+    int rc = qg_walk_step_device(w, actions, p->d_obs33, reward, done, components, stream);
+    if (rc != QG_OK) return rc;
+    int threads = 128, blocks = (s->n + threads - 1) / threads;
+    hipLaunchKernelGGL(qg_po_frame_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, p->kp, p->st, s->n, (const float *)p->d_obs33,
+                       (const float *)w->st.eff_actions, (const float *)s->st.qpos, (const float *)w->st.vel, (const float *)w->st.head,
+                       (const uint8_t *)done, obs, terminal_obs);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *reward, uint8_t *done, float *components, float *terminal_obs) {
+    if (!p || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_po_step: null argument");
+    qg_walk *w = p->walk;
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    size_t n = (size_t)s->n, width = (size_t)p->kp.window * QG_PO_FRAME;
+    HIP_TRY(hipMemcpyAsync(w->d_actions, actions, n * 12 * 4, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
+    int rc = qg_po_step_device(p, w->d_actions, p->d_out, w->d_reward, w->d_done, components ? w->d_comps : nullptr,
+                               terminal_obs ? p->d_term : nullptr, s->stream);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(obs, p->d_out, n * width * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipMemcpyAsync(reward, w->d_reward, n * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipMemcpyAsync(done, w->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    if (components) HIP_TRY(hipMemcpyAsync(components, w->d_comps, n * QG_NWALKREWARD * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, p->d_term, n * width * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
     return QG_OK;
 }

@@ -218,3 +218,101 @@ class WalkingQuadrupedEnv:
 
     def close(self):
         self._vec.close()
+
+
+class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
+    """Batched ``POWalkingQuadrupedEnv`` (``src/envs/po_walking_quad.py``): the observation is the stack of the last
+    ``obs_window`` 26-value frames [gyro, accel, Madgwick-IMU Euler angles, body_vel xy, data.ctrl, command vx vy theta]
+    (``:48-56``); rewards and terminations are the walking task's."""
+
+    FRAME = 26
+
+    def __init__(self, num_envs, obs_window=1, **kwargs):
+        super().__init__(num_envs, **kwargs)
+        self.obs_window = int(obs_window)
+        h = C.c_void_p()
+        check(self._lib.qg_po_create(self._w, self.obs_window, C.byref(h)), "qg_po_create")
+        self._po = h
+        self.obs_dim = int(self._lib.qg_po_obs_dim(self._po))
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.obs_dim,), dtype=np.float32)   # po_walking_quad.py:27
+
+    def reset(self):
+        obs = np.empty((self.num_envs, self.obs_dim), np.float32)
+        check(self._lib.qg_po_reset(self._po, None, self._seed, self._flags, obs.ctypes.data), "qg_po_reset")
+        if self.random_controls:
+            self._resample(range(self.num_envs))
+        return obs
+
+    def step_wait(self):
+        n = self.num_envs
+        a = self._actions
+        if a.shape != (n, 12):
+            raise ValueError(f"actions must have shape ({n}, 12)")
+        obs = np.empty((n, self.obs_dim), np.float32)
+        term = np.empty((n, self.obs_dim), np.float32)
+        rew = np.empty(n, np.float32)
+        done = np.empty(n, np.uint8)
+        comps = np.empty((n, NWALKREWARD), np.float32)
+        check(self._lib.qg_po_step(self._po, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, comps.ctypes.data,
+                                   term.ctypes.data), "qg_po_step")
+        dones = done.astype(bool)
+        infos = []
+        for i in range(n):
+            info = {k: float(comps[i, j]) for j, k in enumerate(REWARD_KEYS)}
+            if dones[i]:
+                info["terminal_observation"] = term[i].copy()
+                info["TimeLimit.truncated"] = False
+            infos.append(info)
+        if dones.any() and self.random_controls:
+            self._resample(np.nonzero(dones)[0])
+        self.last_components = comps
+        return obs, rew, dones, infos
+
+    def close(self):
+        if getattr(self, "_po", None):
+            self._lib.qg_po_destroy(self._po)
+            self._po = None
+        super().close()
+
+
+class POWalkingQuadrupedEnv:
+    """One robot with the reference's constructor ``POWalkingQuadrupedEnv(obs_window=1, **kwargs)``
+    (``po_walking_quad.py:10``; ``train_quadruped.py:16-22`` builds it with ``obs_window=10``)."""
+
+    reward_keys = REWARD_KEYS
+
+    def __init__(self, obs_window=1, **kwargs):
+        allowed = {"settling_time", "random_controls", "random_init", "reset_options", "model_path", "max_time", "frame_skip", "device"}
+        ignored = {"render_mode", "width", "height", "render_fps", "save_video", "video_path", "use_default_termination",
+                   "reward_fns", "termination_fns"}
+        extra = set(kwargs) - allowed - ignored
+        if extra:
+            raise TypeError(f"unexpected keyword arguments {sorted(extra)}")
+        if kwargs.get("render_mode") is not None or kwargs.get("save_video"):
+            raise NotImplementedError("rendering / video recording is not part of the HIP path")
+        args = {k: v for k, v in kwargs.items() if k in allowed}
+        args.setdefault("model_path", "./models/quadruped/scene.xml")
+        self._vec = POWalkingQuadrupedVecEnv(1, obs_window=obs_window, **args)
+        self.obs_window = obs_window
+        self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
+        self.model = self._vec.model
+        self.info = {}
+
+    def reset(self, seed=None, options=None):
+        if options is not None:
+            self._vec.reset_options = options
+        obs = self._vec.reset()
+        self.info = {}
+        return obs[0].astype(np.float64), self.info
+
+    def step(self, action):
+        obs, rew, dones, infos = self._vec.step(np.asarray(action, np.float32)[None])
+        info = dict(infos[0])
+        term_obs = info.pop("terminal_observation", None)
+        info.pop("TimeLimit.truncated", None)
+        self.info = info
+        out = term_obs if term_obs is not None else obs[0]
+        return out.astype(np.float64), float(rew[0]), bool(dones[0]), False, self.info
+
+    def close(self):
+        self._vec.close()

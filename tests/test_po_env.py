@@ -1,0 +1,84 @@
+"""The partially observable pack (qg_po_*) against oracle/po_oracle.py.  The Madgwick filter of the
+reference comes from the `ahrs` package, which is not available offline: the oracle restates the published
+algorithm -- parity unpinned, stated here.  The oracle is driven with the GPU's own sensor values."""
+import numpy as np
+import pytest
+
+from oracle import po_oracle as P
+
+
+def test_madgwick_restatement_properties():
+    # unit output, no update for an exactly zero gyro, accelerometer pulls the estimate towards gravity
+    q = np.array([0.9, 0.1, -0.2, 0.3]); q /= np.linalg.norm(q)
+    assert np.array_equal(P.madgwick_update_imu(q, [0, 0, 0], [0, 0, 9.8], 0.02), q)
+    q1 = P.madgwick_update_imu(q, [0.3, -0.2, 0.1], [0.1, 0.2, 9.7], 0.02)
+    assert abs(np.linalg.norm(q1) - 1) < 1e-15
+    # pure gyro integration when the accelerometer reads zero: dq = 0.5 q (x) w dt
+    q2 = P.madgwick_update_imu([1, 0, 0, 0], [0, 0, 1.0], [0, 0, 0], 0.01)
+    assert np.allclose(q2, np.array([1, 0, 0, 0.005]) / np.linalg.norm([1, 0, 0, 0.005]))
+    q = np.array([1.0, 0, 0, 0])
+    for _ in range(5000):
+        q = P.madgwick_update_imu(q, [1e-9, 0, 0], [0, 0.5, 9.8], 0.02)
+    assert P.to_angles(q)[0] == pytest.approx(np.arctan2(0.5, 9.8), abs=2e-3)
+    assert np.allclose(P.to_angles([np.cos(0.35), 0, 0, np.sin(0.35)]), [0, 0, 0.7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,settle", [(1, 0.0), (4, 0.08)])
+def test_po_frames_match_oracle(window, settle):
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
+    n, fs = 40, 10
+    env = POWalkingQuadrupedVecEnv(n, obs_window=window, settling_time=settle, frame_skip=fs, max_time=0.6, random_init=True,
+                                   random_controls=True, reset_options={"min_speed": 0.1, "max_speed": 0.4})
+    assert env.observation_space.shape == (26 * window,)                       # po_walking_quad.py:21-27
+    dt = 0.002 * fs
+    o = P.POOracle(n, dt, settle, window)
+    default_ctrl = np.array([0, 0, -0.5] * 4, float)
+    np.random.seed(5)
+    zero_cmd_v, zero_cmd_h = np.zeros(2), np.zeros(2)
+    obs = env.reset()
+    # first reset: estimate [1,0,0,0], commands still zero when the observation is taken (:59-69, control_inputs.py:9-12)
+    for i in range(n):
+        exp = o.reset_env(i, default_ctrl, np.array([1.0, 0, 0, 0]), zero_cmd_v, zero_cmd_h)
+        assert np.allclose(obs[i], exp, atol=1e-6)
+    vel, head = env.velocity.copy(), env.heading.copy()
+    rng = np.random.default_rng(1)
+    t = np.zeros(n)
+    saw_done = False
+    for k in range(70):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        obs, rew, dones, infos = env.step(a)
+        qquat = env._sim.get_state()[0][:, 3:7].astype(np.float64)
+        for _ in range(fs):                       # the engine's clock: one f64 addition per substep
+            t += 0.002
+        for i in range(n):
+            stacked = infos[i]["terminal_observation"] if dones[i] else obs[i]
+            fr = stacked[-26:].astype(np.float64)
+            sens = np.zeros(33); sens[15:18] = fr[0:3]; sens[12:15] = fr[3:6]; sens[30:32] = fr[9:11]
+            # while the estimate aliases qpos, the kernel reads the post-step quaternion; an env that finished has been
+            # reset already, so skip the (rare) aliasing + termination combination
+            exp = o.step_env(i, t[i], sens, fr[11:23], qquat[i], vel[i], head[i])
+            if not (dones[i] and o.alias[i]):
+                assert np.allclose(stacked, exp, rtol=2e-4, atol=2e-4), (k, i)
+            if dones[i]:
+                saw_done = True
+                # reset frame: previous estimate, default ctrl, the command of the episode that just ended
+                exp = o.reset_env(i, default_ctrl, np.array([1.0, 0, 0, 0]), vel[i], head[i])
+                assert np.allclose(obs[i], exp, rtol=2e-4, atol=2e-4), (k, i)
+                t[i] = 0.0
+        vel, head = env.velocity.copy(), env.heading.copy()                  # commands re-sampled after the step
+    assert saw_done
+    env.close()
+
+
+@pytest.mark.gpu
+def test_po_single_env_facade():
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedEnv
+    env = POWalkingQuadrupedEnv(obs_window=10, model_path="builtin", max_time=20, frame_skip=10, settling_time=0.5, random_controls=True,
+                                reset_options={"fixed_heading_angle": 0.0, "fixed_velocity_angle": 0.0, "fixed_speed": 0.3})   # train_quadruped.py:16-46
+    obs, info = env.reset()
+    assert obs.shape == (260,) and env.observation_space.shape == (260,)         # train_quadruped.py:19: 26 x 10
+    obs, r, term, trunc, info = env.step(np.zeros(12, np.float32))
+    assert obs.shape == (260,) and np.allclose(obs[-15:-3], [0, 0, -0.5] * 4)    # settling: joint centres applied
+    assert np.allclose(obs[-3:], [0.3, 0.0, 0.0], atol=1e-6)
+    env.close()
