@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--walking", action="store_true", help="time the walking task layer too (SURVEY 8 f1): pre + physics + post kernels per env-step")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="development only: every rank uses GPU 0 and the gather goes through gloo on CPU copies, to exercise the "
+                         "multi-rank control flow on a one-GPU box (numbers are meaningless)")
     ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
@@ -131,10 +134,15 @@ def main():
         raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.rehearse_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+        if args.rehearse_shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
 
     n = args.envs_per_gpu
     task = _abi.default_task()
@@ -160,7 +168,7 @@ def main():
     gatherer = None
     if world > 1:
         from quadruped_gym_amd.dist import PackedGatherer
-        gatherer = PackedGatherer(n, row, dev, dst=0)
+        gatherer = PackedGatherer(n, row, "cpu" if args.rehearse_shared_gpu else dev, dst=0)
 
     walk = None
     if args.walking:
@@ -186,14 +194,15 @@ def main():
                 continue
             sim.step_device_packed(pool[k & 15], packed[b], stream=compute)
             if gatherer is not None:
-                gatherer.submit(packed[b])               # RCCL gather on the communication stream
-                if len(gatherer.pending) > 1 or args.sync_gather:
-                    gatherer.collect()
+                gatherer.submit(packed[b].cpu() if args.rehearse_shared_gpu else packed[b])   # RCCL gather on the communication stream (ordering by events, no host sync)
+                if args.sync_gather:
+                    gatherer.collect()                   # host waits for every gather: the un-overlapped reference point
+                elif len(gatherer.pending) > 64:
+                    del gatherer.pending[:-2]
 
     def fence():
         if gatherer is not None:
-            while gatherer.pending:
-                gatherer.collect()
+            gatherer.drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

@@ -72,6 +72,15 @@ class PackedGatherer:
             if ev is not None:
                 (stream or self.torch.cuda.current_stream(self.device)).wait_event(ev)
 
+    def drain(self):
+        """Forget the outstanding gathers without reading them (a throughput loop that never looks at the data);
+        buffer reuse stays ordered by ``wait_buffer_free``.  Blocks until the last gather has finished."""
+        self.pending.clear()
+        if self.cuda:
+            for ev in self.done:
+                if ev is not None:
+                    ev.synchronize()
+
     def collect(self):
         b = self.pending.pop(0)
         if self.cuda and self.done[b] is not None:
