@@ -151,6 +151,15 @@ DEV void sincos_f(float x, float &s, float &c) {
     c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// Divergence guard.  The engine being replaced checks positions / velocities / accelerations every step and resets
+// a simulation that produced NaN / Inf or huge values (mj_checkPos / mj_checkVel / mj_checkAcc); here such an env is
+// reported as done (and reset when auto_reset is on).  The device pass is compiled with -ffinite-math-only, so the
+// test reads the exponent bits of a sum of state values instead of using isnan / isinf.
+DEV bool state_is_bad(float probe) {
+    unsigned bits = __builtin_bit_cast(unsigned, probe);
+    return ((bits >> 23) & 0xFFu) >= 0x9Eu;          // NaN, Inf, or magnitude >= 2^31
+}
+
 // counter-based uniform in [0,1) with 24 random bits (same stream as the oracle's qgo_uniform)
 DEV uint64_t mix64(uint64_t x) {
     x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
@@ -681,6 +690,12 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
     if (T->use_flip) done = done || (so.zaxis.z < 0.f);          // walking_quad.py:156-160, on the step's sensordata
+    {
+        float probe = B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) probe += lds[LQ(j) * 64 + lane] + lds[LQD(j) * 64 + lane];
+        done = done || state_is_bad(probe);
+    }
 
     // ---- outputs: stage rows in LDS, then store the wave's contiguous chunk coalesced ------
     const int od = T->obs_mode == 1 ? 21 : 33;
@@ -893,6 +908,11 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
     if (T->use_flip) done = done || (so.zaxis.z < 0.f);          // walking_quad.py:156-160, on the step's sensordata
+    {
+        float probe = L.q[0] + L.q[1] + L.q[2] + L.qd[0] + L.qd[1] + L.qd[2];
+        probe = quad_sum(probe) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+        done = done || state_is_bad(probe);
+    }
 
     const int od = T->obs_mode == 1 ? 21 : 33;
     const int row = P.packed ? od + 2 : od;

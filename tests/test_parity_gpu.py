@@ -268,6 +268,27 @@ def test_full_size_invariants(mapping):
     sim.close(); sim2.close()
 
 
+@pytest.mark.parametrize("mapping", ["lane", "quad"])
+def test_diverged_envs_are_reported_done_and_reset(mapping):
+    """A state with NaN / Inf (here injected through set_state) must not linger: the env is reported done and,
+    with auto_reset, restarts -- the counterpart of the engine's own bad-state reset."""
+    from quadruped_gym_amd.sim import BatchedSim
+    task = _abi.default_task()
+    task.auto_reset = 1
+    sim = BatchedSim(40, task=task)
+    sim.set_mapping(MAPPINGS[mapping])
+    qpos, qvel, act, ctrl, nstep = sim.get_state()
+    qvel[5, 7] = np.nan
+    qpos[21, 2] = np.inf
+    qvel[33, 0] = 1e30
+    sim.set_state(qpos, qvel, act)
+    obs, rew, done, _ = sim.step(np.zeros((40, 12), np.float32))
+    assert done[[5, 21, 33]].all() and done.sum() == 3
+    q1, v1, a1, _, n1 = sim.get_state()
+    assert np.isfinite(q1).all() and np.isfinite(v1).all() and (n1[[5, 21, 33]] == 0).all()
+    sim.close()
+
+
 def test_mappings_agree_with_each_other():
     """The two mappings run the same arithmetic per leg; only the order of the four-leg sums differs,
     so a 50-step rollout from reset stays within rounding-level drift of one another."""
