@@ -781,57 +781,78 @@ DEV void quad_sum(Sym6 &a) { quad_sum(a.AA); quad_sum(a.LL); a.AL.r0 = quad_sum(
 
 struct LegState { float q[3], qd[3], act[3], u[3]; };
 
-DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_sensors, SensorOut &so, float jpos[3]) {
+// Ordered for low register pressure: the leg pass (the widest live set) runs first with only the base context alive;
+// the FRAME terms are built afterwards; sensors go straight to the LDS tile; the rotation is rebuilt at integration.
+// LOWREG: rebuild the base context (cheap) instead of keeping it alive across the leg pass -- pays off once two waves
+// share a SIMD (register cap 256), costs ~2 % when a wave has the register file to itself.
+template <bool LOWREG>
+DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
     const KModel &C = QG_BAKED_MODEL;
     const float h = C.h;
-    const BaseCtx bc = base_prelude(C, B);
-    if (want_sensors) {
-        so.pw = B.pw; so.vw = B.vw; so.wb = B.wb; so.vb = bc.vb;
-        so.xaxis = bc.cx; so.zaxis = bc.cz;
-        jpos[0] = L.q[0]; jpos[1] = L.q[1]; jpos[2] = L.q[2];
-    }
-    SV p0;
-    Sym6 Ic0;
-    frame_body(C, bc, h, p0, Ic0);
-    {   // FRAME contact: this lane evaluates its quarter turn of the three base sample points
-        float wsum = 0.f;
-        V3 s = v3(0.f, 0.f, 0.f);
-        float zb = C.contact_margin - B.pw.z;
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            V3 r0 = ld3(C.cp0[4 * o]);
-            V3 r = v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z);
-            contact_point(r, bc.n, zb, wsum, s);
+    const BaseCtx bc0 = base_prelude(C, B);
+    V3 gb_keep;
+    Sym6 Ic;
+    SV fc, Fu;
+    float Y0[6], Y1[6], Y2[6], u[3];
+    {
+        const BaseCtx &bc = bc0;
+        gb_keep = bc.gb;
+        if (want_sensors) {          // the step's sensordata describes the state at the start of its last substep
+            zaxis_z = bc.cz.z;
+            row[3 * k + 0] = L.q[0]; row[3 * k + 1] = L.q[1]; row[3 * k + 2] = L.q[2];
+            if (k == 0) {
+                row[15] = B.wb.x; row[16] = B.wb.y; row[17] = B.wb.z;
+                row[18] = B.pw.x; row[19] = B.pw.y; row[20] = B.pw.z;
+                row[21] = B.vw.x; row[22] = B.vw.y; row[23] = B.vw.z;
+                row[24] = bc.cx.x; row[25] = bc.cx.y; row[26] = bc.cx.z;
+                row[27] = bc.cz.x; row[28] = bc.cz.y; row[29] = bc.cz.z;
+                row[30] = bc.vb.x; row[31] = bc.vb.y; row[32] = bc.vb.z;
+            }
         }
-        wsum = quad_sum(wsum);
-        s = quad_sum(s);
-        Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-        SV fe;
-        contact_finish(wsum, s, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
-        p0.a = p0.a - fe.a;
-        p0.l = p0.l - fe.l;
+        // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
+        Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
+        Sym6 YFt;
+        SV F[3];
+        float Hd[3], H01, H02, H12, bj[3];
+        leg_pass<true, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+        leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
+        sub(Ic, YFt);                       // this leg's Schur complement
     }
-    // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
-    Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
-    Sym6 Ic, YFt;
-    SV fc, F[3], Fu;
-    float Hd[3], H01, H02, H12, bj[3], Y0[6], Y1[6], Y2[6], u[3];
-    leg_pass<true, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
-    leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
-    sub(Ic, YFt);                       // this leg's Schur complement
     quad_sum(Ic);
     fc.a = quad_sum(fc.a); fc.l = quad_sum(fc.l);
     Fu.a = quad_sum(Fu.a); Fu.l = quad_sum(Fu.l);
-    add(Ic0, Ic);
     float x6[6];
     {
+        const BaseCtx bc = LOWREG ? base_prelude(C, B) : bc0;      // rebuilt (cheap) rather than kept alive across the leg pass
+        SV p0;
+        Sym6 Ic0;
+        frame_body(C, bc, h, p0, Ic0);
+        {   // FRAME contact: this lane evaluates its quarter turn of the three base sample points
+            float wsum = 0.f;
+            V3 s = v3(0.f, 0.f, 0.f);
+            float zb = C.contact_margin - B.pw.z;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                V3 r0 = ld3(C.cp0[4 * o]);
+                V3 r = v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z);
+                contact_point(r, bc.n, zb, wsum, s);
+            }
+            wsum = quad_sum(wsum);
+            s = quad_sum(s);
+            Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+            SV fe;
+            contact_finish(wsum, s, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
+            p0.a = p0.a - fe.a;
+            p0.l = p0.l - fe.l;
+        }
+        add(Ic0, Ic);
         SV b = {v3(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a, v3(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l};
         base_solve(Ic0, b, x6);
     }
     V3 wdot = v3(x6[0], x6[1], x6[2]);
     V3 acl = v3(x6[3], x6[4], x6[5]);
-    if (want_sensors) {
-        so.accel[0] = acl.x - bc.gb.x; so.accel[1] = acl.y - bc.gb.y; so.accel[2] = acl.z - bc.gb.z;
+    if (want_sensors && k == 0) {
+        row[12] = acl.x - gb_keep.x; row[13] = acl.y - gb_keep.y; row[14] = acl.z - gb_keep.z;   // accelerometer
     }
     // back-substitution and integration of this lane's three hinges
     const float *Y[3] = {Y0, Y1, Y2};
@@ -844,7 +865,10 @@ DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_s
         L.q[i] = fmaf(h, L.qd[i], L.q[i]);
         L.act[i] = fmaf(L.u[i] - L.act[i], C.link[i].act_decay, L.act[i]);
     }
-    base_integrate(bc, h, wdot, acl, B);
+    {
+        const BaseCtx bc = LOWREG ? base_prelude(C, B) : bc0;
+        base_integrate(bc, h, wdot, acl, B);
+    }
 }
 
 #define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
@@ -888,17 +912,19 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
     }
     ssq = quad_sum(ssq);
 
-    SensorOut so;
-    float jpos[3];
+    // the sensor values of the step go straight into this env's row of the output tile (full 33-value layout; the
+    // 21-value pack is compacted below)
+    float *srow = tile + el * 35;
+    float zaxis_z = 1.f;
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep_quad(cm, sm, B, L, lag && (s == fs - 1), so, jpos);
+    for (int s = 0; s < fs; ++s) substep_quad<(WPE > 1)>(cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
     nstep += fs;
     if (!lag) {
         BaseState B2 = B;
         LegState L2 = L;
-        substep_quad(cm, sm, B2, L2, true, so, jpos);
+        substep_quad<(WPE > 1)>(cm, sm, B2, L2, true, srow, k, zaxis_z);
     }
 
     float c_fwd = T->w_forward * B.vw.x;
@@ -907,7 +933,6 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
     float reward = c_fwd + c_ctl + c_alive;
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
-    if (T->use_flip) done = done || (so.zaxis.z < 0.f);          // walking_quad.py:156-160, on the step's sensordata
     {
         float probe = L.q[0] + L.q[1] + L.q[2] + L.qd[0] + L.qd[1] + L.qd[2];
         probe = quad_sum(probe) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
@@ -916,30 +941,24 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
 
     const int od = T->obs_mode == 1 ? 21 : 33;
     const int row = P.packed ? od + 2 : od;
-    {
-        float *r = tile + el * row;
-        r[3 * k + 0] = jpos[0]; r[3 * k + 1] = jpos[1]; r[3 * k + 2] = jpos[2];
-        if (k == 0) {
-            r[12] = so.accel[0]; r[13] = so.accel[1]; r[14] = so.accel[2];
-            r[15] = so.wb.x; r[16] = so.wb.y; r[17] = so.wb.z;
-            if (od == 33) {
-                r[18] = so.pw.x; r[19] = so.pw.y; r[20] = so.pw.z;
-                r[21] = so.vw.x; r[22] = so.vw.y; r[23] = so.vw.z;
-                r[24] = so.xaxis.x; r[25] = so.xaxis.y; r[26] = so.xaxis.z;
-                r[27] = so.zaxis.x; r[28] = so.zaxis.y; r[29] = so.zaxis.z;
-                r[30] = so.vb.x; r[31] = so.vb.y; r[32] = so.vb.z;
-            } else {
-                r[18] = so.vb.x; r[19] = so.vb.y; r[20] = so.vb.z;
-            }
-            if (P.packed) { r[od] = reward; r[od + 1] = done ? 1.f : 0.f; }
-        }
+    if (T->use_flip) done = done || (zaxis_z < 0.f);              // walking_quad.py:156-160, on the step's sensordata
+    if (k == 0) {                                                  // lane 0 of the quad wrote these entries itself
+        if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
+        if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
     __syncthreads();
     {
         const int live_envs = min(QGK_QUAD_ENVS, n - env0);
         const int total = live_envs * row;
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
-        for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+        if (row == 35) {                       // rows were staged with a stride of 35 floats: the packed full layout is a straight copy
+            for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+        } else {
+            for (int e = lane; e < total; e += QGK_WAVE) {
+                int er = e / row, ec = e - er * row;
+                dst[e] = tile[er * 35 + ec];
+            }
+        }
     }
     const bool lead = live && k == 0;
     if (lead && !P.packed) {
