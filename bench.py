@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="development only: every rank uses GPU 0 and the gather goes through gloo on CPU copies, to exercise the "
                          "multi-rank control flow on a one-GPU box (numbers are meaningless)")
+    ap.add_argument("--generic-model", action="store_true", help="perturb one mass by 1e-3 so the table-driven (generic) kernel variant runs")
     ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
@@ -152,7 +153,11 @@ def main():
     task.fall_height = 0.05
     task.auto_reset = 1
     task.reset_flags = _abi.RESET_RANDOM_YAW if args.random_yaw else 0
-    sim = BatchedSim(n, device=local_rank, task=task, env_index_base=rank * n)
+    model = None
+    if args.generic_model:
+        model = _abi.default_model()
+        model.body_mass[3] *= 1.001
+    sim = BatchedSim(n, device=local_rank, model=model, task=task, env_index_base=rank * n)
     sim.set_track_ctrl(False)
     sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD}[args.mapping])
     mapping_name = {_abi.MAP_LANE: "one env per lane", _abi.MAP_QUAD: "one leg per lane (4 lanes per env)"}[sim.mapping]
@@ -252,7 +257,8 @@ def main():
                                    + (", random yaw at reset" if args.random_yaw else "")
                                    + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
                                    + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if world > 1 else ""),
-                       "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name},
+                       "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name,
+                       "constants": "baked literals" if sim.baked else "tables (LDS / scalar loads)"},
             "substeps_per_sec": value * args.frame_skip,
             "state_finite": healthy,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

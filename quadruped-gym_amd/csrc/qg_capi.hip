@@ -204,9 +204,9 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
 
 // The one-leg-per-lane kernel (16 envs per wave, ~3.5x fewer instructions per wave, no LDS scratch, lower
 // register pressure) measured faster than one env per lane at every batch size from 1 Ki to 256 Ki envs
-// (profiles/r01/sweep.txt), so AUTO picks it whenever the model is the compiled-in robot it needs.
+// (profiles/r01/sweep.txt), so AUTO picks it.  The compiled-in robot runs the variant with literal constants; any other
+// numbers run the variant that stages the model tables in LDS.
 static int effective_mapping(const qg_sim *s) {
-    if (!s->baked) return QG_MAP_LANE;
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
     return QG_MAP_QUAD;
 }
@@ -229,10 +229,14 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     if (effective_mapping(s) == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
-        if (qblocks <= 1024)      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
-            hipLaunchKernelGGL(qg_step_kernel_quad<1>, dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
-        else
-            hipLaunchKernelGGL(qg_step_kernel_quad<2>, dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
+        const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
+        if (s->baked) {
+            if (one_wave) hipLaunchKernelGGL((qg_step_kernel_quad<1, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+            else hipLaunchKernelGGL((qg_step_kernel_quad<2, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+        } else {
+            if (one_wave) hipLaunchKernelGGL((qg_step_kernel_quad<1, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+            else hipLaunchKernelGGL((qg_step_kernel_quad<2, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+        }
     } else if (s->baked)
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
     else
@@ -340,8 +344,6 @@ extern "C" int qg_time_step_kernel(qg_sim *s, const float *d_actions, float *d_p
 extern "C" int qg_set_mapping(qg_sim *s, int32_t mapping) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     if (mapping != QG_MAP_AUTO && mapping != QG_MAP_LANE && mapping != QG_MAP_QUAD) return fail(QG_ERR_ARG, "qg_set_mapping: unknown mapping %d", mapping);
-    if (mapping == QG_MAP_QUAD && !s->baked)
-        return fail(QG_ERR_ARG, "qg_set_mapping: the one-leg-per-lane kernel serves the compiled-in robot only (legs must be quarter-turn copies)");
     s->mapping = mapping;
     return QG_OK;
 }

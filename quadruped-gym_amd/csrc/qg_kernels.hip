@@ -764,7 +764,8 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
 // no LDS, no run-time indexed arrays.  A wave carries 16 envs, so 4096 envs fill 256 waves
 // instead of 64: at batch sizes that cannot fill the chip with one env per lane this cuts the
 // instructions per wave (= the time, a lone wave issues one VALU instruction per 4 cycles) ~3.5x.
-// Needs the default (baked) robot: the legs are quarter-turn copies of one another.
+// BAKED variant: the compiled-in robot, whose legs are quarter-turn copies of one another (constants become literals).
+// Generic variant: any model numbers; the tables are staged in LDS and each lane reads its own leg's rows.
 // ------------------------------------------------------------------------------------------
 template <int CTRL> DEV float dpp_quad(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
@@ -785,9 +786,10 @@ struct LegState { float q[3], qd[3], act[3], u[3]; };
 // the FRAME terms are built afterwards; sensors go straight to the LDS tile; the rotation is rebuilt at integration.
 // LOWREG: rebuild the base context (cheap) instead of keeping it alive across the leg pass -- pays off once two waves
 // share a SIMD (register cap 256), costs ~2 % when a wave has the register file to itself.
-template <bool LOWREG>
-DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
-    const KModel &C = QG_BAKED_MODEL;
+// BAKED: the compiled-in robot, constants are literals and the lane works in its leg's quarter-turn frame.  Otherwise `C`
+// is the model table staged in LDS and every lane reads the constants of its own leg (k) from it -- any model numbers.
+template <bool BAKED, bool LOWREG>
+DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
     const float h = C.h;
     const BaseCtx bc0 = base_prelude(C, B);
     V3 gb_keep;
@@ -809,12 +811,17 @@ DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_s
                 row[30] = bc.vb.x; row[31] = bc.vb.y; row[32] = bc.vb.z;
             }
         }
-        // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
-        Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
         Sym6 YFt;
         SV F[3];
         float Hd[3], H01, H02, H12, bj[3];
-        leg_pass<true, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+        if constexpr (BAKED) {
+            // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
+            Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
+            leg_pass<true, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+        } else {
+            Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+            leg_pass<false, false>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+        }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
     }
@@ -833,9 +840,12 @@ DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_s
             float zb = C.contact_margin - B.pw.z;
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
-                V3 r0 = ld3(C.cp0[4 * o]);
-                V3 r = v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z);
-                contact_point(r, bc.n, zb, wsum, s);
+                if constexpr (BAKED) {
+                    V3 r0 = ld3(C.cp0[4 * o]);
+                    contact_point(v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z), bc.n, zb, wsum, s);
+                } else {
+                    contact_point(ld3(C.cp0[3 * k + o]), bc.n, zb, wsum, s);   // any partition of the 12 points over the 4 lanes
+                }
             }
             wsum = quad_sum(wsum);
             s = quad_sum(s);
@@ -863,7 +873,7 @@ DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_s
         for (int r = 0; r < 6; ++r) acc = fmaf(-Y[i][r], x6[r], acc);
         L.qd[i] = fmaf(h, acc, L.qd[i]);
         L.q[i] = fmaf(h, L.qd[i], L.q[i]);
-        L.act[i] = fmaf(L.u[i] - L.act[i], C.link[i].act_decay, L.act[i]);
+        L.act[i] = fmaf(L.u[i] - L.act[i], link_of<BAKED>(C, k, i).act_decay, L.act[i]);
     }
     {
         const BaseCtx bc = LOWREG ? base_prelude(C, B) : bc0;
@@ -875,11 +885,18 @@ DEV void substep_quad(float cm, float sm, BaseState &B, LegState &L, bool want_s
 
 // WPE = waves per SIMD the register allocation is capped for: 1 (all 512 registers) is fastest while the grid has at
 // most one wave per SIMD (n <= 16384); 2 lets a second wave share the SIMD once the grid is larger.
-template <int WPE>
-__global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask *__restrict__ T, KStepArgs P) {
-    const KModel &C = QG_BAKED_MODEL;
+template <int WPE, bool BAKED>
+__global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P) {
     __shared__ float tile[QGK_QUAD_ENVS * 35];
+    __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
     const int lane = threadIdx.x;
+    if constexpr (!BAKED) {
+        const float *src = reinterpret_cast<const float *>(Mp);
+        float *dst = reinterpret_cast<float *>(&smodel);
+        for (int i = lane; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE) dst[i] = src[i];
+        __syncthreads();
+    }
+    const KModel &C = BAKED ? QG_BAKED_MODEL : smodel;
     const int k = lane & 3;                         // leg of this lane
     const int el = lane >> 2;                       // env within the wave
     const int env0 = blockIdx.x * QGK_QUAD_ENVS;
@@ -905,7 +922,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
         float a = fminf(fmaxf(P.actions[(size_t)env * 12 + j], -1.f), 1.f);    // quadruped.py:160
         aclip[i] = a;
         ssq = fmaf(a, a, ssq);
-        L.u[i] = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
+        L.u[i] = fminf(fmaxf(a, link_of<BAKED>(C, k, i).ctrl_lo), link_of<BAKED>(C, k, i).ctrl_hi);
         L.q[i] = P.st.qpos[(7 + j) * n + env];
         L.qd[i] = P.st.qvel[(6 + j) * n + env];
         L.act[i] = P.st.act[j * n + env];
@@ -919,12 +936,12 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep_quad<(WPE > 1)>(cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
+    for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
     nstep += fs;
     if (!lag) {
         BaseState B2 = B;
         LegState L2 = L;
-        substep_quad<(WPE > 1)>(cm, sm, B2, L2, true, srow, k, zaxis_z);
+        substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B2, L2, true, srow, k, zaxis_z);
     }
 
     float c_fwd = T->w_forward * B.vw.x;
@@ -996,7 +1013,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KTask
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int j = 3 * k + i;
-            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : L.q[i];
+            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : L.q[i];
             P.st.qvel[(6 + j) * n + env] = rst ? 0.f : L.qd[i];
             P.st.act[j * n + env] = rst ? 0.f : L.act[i];
             if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
