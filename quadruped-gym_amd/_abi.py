@@ -113,6 +113,13 @@ def load_library():
             f"{path} is missing: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C quadruped-gym_amd/csrc`). "
             "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as the system's).  Loaded after
+    # ours it becomes a SECOND runtime and torch then finds no GPU; loaded first, libquadgym.so's dependency resolves
+    # to that same copy.  So when torch is installed, load it before the library.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(path)
     vp, u8p, fp, i32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
     lib.qg_version.restype = C.c_char_p

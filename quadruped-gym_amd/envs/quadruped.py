@@ -127,26 +127,29 @@ class QuadrupedEnv(EnvBase):
         return self.data.time >= self.max_time
 
     def step(self, action):
-        action = np.clip(action, self.action_space.low, self.action_space.high)
+        # contract of quadruped.py:153-182 -- clip to the action space, frame_skip physics substeps in one launch,
+        # lagged sensordata as the observation, reward / termination callables evaluated on the host mirror
+        lo, hi = self.action_space.low, self.action_space.high
+        applied = np.minimum(np.maximum(np.asarray(action, dtype=np.float64), lo), hi)
         self._push_if_edited()
-        obs, _, _, _ = self._sim.step(np.asarray(action, dtype=np.float32)[None])
+        sensed = self._sim.step(applied.astype(np.float32)[None])[0]
         self._pull()
-        for _ in range(self.frame_skip):                    # the engine's f64 clock: time += timestep per substep
-            self.data.time += self.model.opt.timestep
-        self.data.ctrl[:] = action
-        self.data.sensordata[:] = obs[0]
-        observation = self._get_obs()
+        h = self.model.opt.timestep
+        for _ in range(self.frame_skip):                    # the engine's f64 clock: one addition per substep
+            self.data.time += h
+        self.data.ctrl[:] = applied
+        self.data.sensordata[:] = sensed[0]
 
-        total_reward = 0.0
-        reward_info = {}
-        for name, fn in self.reward_fns.items():
-            r = fn()
-            reward_info[name] = r
-            total_reward += r
-        terminated = any(fn() for fn in self.termination_fns.values())
-        truncated = False
-        info = {"time": self.data.time, "reward_components": reward_info}
-        return observation, total_reward, terminated, truncated, info
+        components = {name: fn() for name, fn in self.reward_fns.items()}
+        total = 0.0
+        for value in components.values():
+            total += value
+        finished = False
+        for fn in self.termination_fns.values():            # `any(...)`: stops at the first condition that fires
+            if fn():
+                finished = True
+                break
+        return self._get_obs(), total, finished, False, {"time": self.data.time, "reward_components": components}
 
     def render(self):
         return None
