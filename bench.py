@@ -118,6 +118,8 @@ def main():
                     help="development only: every rank uses GPU 0 and the gather goes through gloo on CPU copies, to exercise the "
                          "multi-rank control flow on a one-GPU box (numbers are meaningless)")
     ap.add_argument("--generic-model", action="store_true", help="perturb one mass by 1e-3 so the table-driven (generic) kernel variant runs")
+    ap.add_argument("--force-gather", action="store_true", help="run the per-step gather even with one rank (measures its host-side cost)")
+    ap.add_argument("--gather-op", choices=["gather", "all_gather"], default="gather", help="collective used for the per-step exchange")
     ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
@@ -139,11 +141,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.rehearse_shared_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL on ROCm
 
     n = args.envs_per_gpu
     task = _abi.default_task()
@@ -171,9 +176,9 @@ def main():
     packed = [torch.empty((n, row), device=dev) for _ in range(2)]
     compute = torch.cuda.current_stream(dev)
     gatherer = None
-    if world > 1:
+    if use_dist:
         from quadruped_gym_amd.dist import PackedGatherer
-        gatherer = PackedGatherer(n, row, "cpu" if args.rehearse_shared_gpu else dev, dst=0)
+        gatherer = PackedGatherer(n, row, "cpu" if args.rehearse_shared_gpu else dev, dst=0, op=args.gather_op)
 
     walk = None
     if args.walking:
@@ -188,6 +193,8 @@ def main():
         w_obs = torch.empty((n, 33), device=dev); w_rew = torch.empty(n, device=dev)
         w_done = torch.empty(n, device=dev, dtype=torch.uint8); w_comp = torch.empty((n, 11), device=dev)
 
+    step_fn = sim.bind_step_packed(pool, packed, stream=compute)
+
     def run(k0, count):
         for k in range(k0, k0 + count):
             b = k & 1
@@ -197,7 +204,7 @@ def main():
                 check(lib.qg_walk_step_device(walk, pool[k & 15].data_ptr(), w_obs.data_ptr(), w_rew.data_ptr(), w_done.data_ptr(),
                                               w_comp.data_ptr(), C.c_void_p(compute.cuda_stream)), "qg_walk_step_device")
                 continue
-            sim.step_device_packed(pool[k & 15], packed[b], stream=compute)
+            step_fn(k & 15, b)
             if gatherer is not None:
                 gatherer.submit(packed[b].cpu() if args.rehearse_shared_gpu else packed[b])   # RCCL gather on the communication stream (ordering by events, no host sync)
                 if args.sync_gather:
@@ -209,7 +216,7 @@ def main():
         if gatherer is not None:
             gatherer.drain()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -223,7 +230,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the stream the kernel runs on
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -256,7 +263,7 @@ def main():
                                    f"obs={od} f32, U(-1,1) actions resident in HBM"
                                    + (", random yaw at reset" if args.random_yaw else "")
                                    + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
-                                   + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if world > 1 else ""),
+                                   + (f", per-step RCCL {args.gather_op} of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if use_dist else ""),
                        "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name,
                        "constants": "baked literals" if sim.baked else "tables (LDS / scalar loads)"},
             "substeps_per_sec": value * args.frame_skip,
@@ -278,7 +285,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     sim.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

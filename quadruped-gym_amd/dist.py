@@ -18,14 +18,18 @@ def shard_range(total_envs: int, world: int, rank: int):
 
 
 class PackedGatherer:
-    """Per-step gather of the packed rollout buffer to ``dst``, double-buffered so that the gather of
-    step t overlaps the physics of step t+1 when the buffers live on a GPU.
+    """Per-step exchange of the packed rollout buffer, double-buffered so that the collective of step t overlaps the
+    physics of step t+1 when the buffers live on a GPU.
 
-    ``submit(packed)`` enqueues the gather of this step's buffer; ``collect()`` waits for the oldest
-    outstanding gather and returns the ``[world * n, row]`` tensor on ``dst`` (``None`` elsewhere).
+    ``submit(packed)`` issues the collective asynchronously (``async_op=True``: RCCL runs it on the process group's own
+    stream, ordered after the work already queued on the current stream) and returns at once; ``wait_buffer_free()``
+    makes the current stream wait for the collective that read the buffer about to be overwritten (two submits ago) --
+    stream-level ordering on a GPU, no host synchronisation; ``collect()`` waits for the oldest outstanding collective
+    and returns the ``[world * n, row]`` tensor (on ``dst`` for ``op="gather"``, on every rank for ``"all_gather"``).
+    Host-side cost per step is one collective call (measured with a 1-rank RCCL group: see DESIGN.md).
     """
 
-    def __init__(self, n_local: int, row: int, device, dst: int = 0, group=None):
+    def __init__(self, n_local: int, row: int, device, dst: int = 0, group=None, op: str = "gather"):
         import torch
         import torch.distributed as dist
         self.dist = dist
@@ -34,57 +38,54 @@ class PackedGatherer:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.dst = dst
+        self.op = op              # "gather": rows land on dst only; "all_gather": every rank receives them (one ring collective)
         self.n, self.row = int(n_local), int(row)
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.out = None
-        if self.rank == dst:
+        if self.rank == dst or op == "all_gather":
             self.out = [torch.empty((self.world, self.n, self.row), device=self.device, dtype=torch.float32) for _ in range(2)]
-        self.comm = torch.cuda.Stream(self.device) if self.cuda else None
-        self.done = [None, None]
+        self.flat = [o.view(self.world * self.n, self.row) for o in self.out] if self.out is not None else None
+        self.lists = [[o[r] for r in range(self.world)] for o in self.out] if (self.out is not None and op == "gather") else None
+        self.work = [None, None]
         self.k = 0
         self.pending = []
 
     def submit(self, packed):
-        torch, dist = self.torch, self.dist
-        assert tuple(packed.shape) == (self.n, self.row) and packed.dtype == torch.float32
+        dist = self.dist
         b = self.k & 1
-        glist = [self.out[b][r] for r in range(self.world)] if self.rank == self.dst else None
-        if self.cuda:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(self.comm):
-                self.comm.wait_event(ready)
-                dist.gather(packed, glist, dst=self.dst, group=self.group)
-                ev = torch.cuda.Event()
-                ev.record(self.comm)
-            self.done[b] = ev
+        if self.op == "all_gather":
+            w = dist.all_gather_into_tensor(self.flat[b], packed, group=self.group, async_op=True)
         else:
-            dist.gather(packed, glist, dst=self.dst, group=self.group)
+            w = dist.gather(packed, self.lists[b] if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        self.work[b] = w
         self.pending.append(b)
         self.k += 1
 
     def wait_buffer_free(self, stream=None):
-        """Make ``stream`` (default: current) wait until the gather that read the buffer about to be
-        overwritten (two submits ago) has finished."""
-        if self.cuda and self.k >= 2:
-            ev = self.done[self.k & 1]
-            if ev is not None:
-                (stream or self.torch.cuda.current_stream(self.device)).wait_event(ev)
+        """Order the current stream after the collective that read the buffer about to be overwritten (two submits ago)."""
+        w = self.work[self.k & 1]
+        if w is not None:
+            w.wait()              # NCCL/RCCL: the current stream waits; gloo: the host waits
+            self.work[self.k & 1] = None
 
     def drain(self):
-        """Forget the outstanding gathers without reading them (a throughput loop that never looks at the data);
-        buffer reuse stays ordered by ``wait_buffer_free``.  Blocks until the last gather has finished."""
+        """Finish every outstanding collective (a throughput loop that never looks at the data)."""
         self.pending.clear()
+        for b in (0, 1):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
         if self.cuda:
-            for ev in self.done:
-                if ev is not None:
-                    ev.synchronize()
+            self.torch.cuda.synchronize(self.device)
 
     def collect(self):
         b = self.pending.pop(0)
-        if self.cuda and self.done[b] is not None:
-            self.done[b].synchronize()
-        if self.rank != self.dst:
+        if self.work[b] is not None:
+            self.work[b].wait()
+            self.work[b] = None
+        if self.cuda:
+            self.torch.cuda.current_stream(self.device).synchronize()
+        if self.out is None:
             return None
-        return self.out[b].view(self.world * self.n, self.row)
+        return self.flat[b]

@@ -103,6 +103,24 @@ class BatchedSim:
         check(self._lib.qg_step_device_packed(self._h, actions.data_ptr(), packed.data_ptr(), self._stream_ptr(stream)),
               "qg_step_device_packed")
 
+    def bind_step_packed(self, actions_list, packed_list, stream=None):
+        """Pre-validate a set of action / packed tensors and return ``step(i, j)`` that launches one env-step on
+        ``actions_list[i] -> packed_list[j]`` with no per-call checks (a throughput loop's hot path)."""
+        import torch
+        for a in actions_list:
+            self._check_tensor(a, (self.n, NU), torch.float32)
+        for p in packed_list:
+            self._check_tensor(p, (self.n, self.obs_dim + 2), torch.float32)
+        a_ptr = [C.c_void_p(a.data_ptr()) for a in actions_list]
+        p_ptr = [C.c_void_p(p.data_ptr()) for p in packed_list]
+        st = self._stream_ptr(stream)
+        fn, h = self._lib.qg_step_device_packed, self._h
+
+        def step(i, j):
+            if fn(h, a_ptr[i], p_ptr[j], st) != 0:
+                check(-1, "qg_step_device_packed")
+        return step
+
     def time_step_kernel(self, actions, packed, iters: int) -> float:
         """Mean milliseconds per launch of the step kernel over ``iters`` back-to-back launches,
         measured with HIP events on the stream the kernel is launched on."""
