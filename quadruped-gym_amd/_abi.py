@@ -95,7 +95,8 @@ def package_dir() -> str:
 
 
 def library_path() -> str:
-    return os.path.join(package_dir(), "csrc", "libquadgym.so")
+    # QUADGYM_LIB selects another build of the same library (A/B timing of kernel variants on one box)
+    return os.environ.get("QUADGYM_LIB") or os.path.join(package_dir(), "csrc", "libquadgym.so")
 
 
 _lib = None

@@ -274,7 +274,7 @@ DEV void frame_body(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic
 // Out: leg composite inertia Ic and force fc (to be added to the base rows), the base coupling
 // columns F[j], the leg block H = [[Hd0,H01,H02],[.,Hd1,H12],[.,.,Hd2]] and the right-hand side b.
 // ------------------------------------------------------------------------------------------
-template <bool BAKED, bool QUAD>
+template <bool BAKED, bool QUAD, bool CULL_FEMUR = false>
 DEV void leg_pass(const KModel &C, int k, Fr Ep, const float q[3], const float qd[3], const float act[3], const BaseCtx &bc, float zbase,
                   float h, Sym6 &Ic, SV &fc, SV F[3], float Hd[3], float &H01, float &H02, float &H12, float bj[3]) {
     V3 pp = v3(0.f, 0.f, 0.f);
@@ -321,11 +321,24 @@ DEV void leg_pass(const KModel &C, int k, Fr Ep, const float q[3], const float q
         f[i].a = Ia.a + cross(v.a, Iv.a) + cross(v.l, Iv.l);
         f[i].l = Ia.l + cross(v.a, Iv.l);
         Ag[i] = sym6_of(Bi);
-        SV fe;
-        body_contact<QGK_CP_LINK>(L.cp, E, p, zbase + dot(bc.n, p), bc.n, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
-                                  C.contact_margin, C.contact_mu, h, fe, Ag[i]);
-        f[i].a = f[i].a - fe.a;
-        f[i].l = f[i].l - fe.l;
+        float zo = zbase + dot(bc.n, p);
+        bool may = true;
+        if (CULL_FEMUR && i == 0) {
+            // femur: wave-uniform skip of its contact when no env of the wave can reach the floor with it (bounding sphere
+            // of its sample points).  Pays only once several waves share a SIMD (+4.7 % at 262 144 envs, -1.6 % at 4096).
+            float b2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < QGK_CP_LINK; ++q) b2 = fmaxf(b2, L.cp[q][0] * L.cp[q][0] + L.cp[q][1] * L.cp[q][1] + L.cp[q][2] * L.cp[q][2]);
+            float reach = zo - C.contact_margin;
+            may = __any(!(reach > 0.f) || reach * reach < b2 * 1.0002f) != 0;
+        }
+        if (may) {
+            SV fe;
+            body_contact<QGK_CP_LINK>(L.cp, E, p, zo, bc.n, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
+                                      C.contact_margin, C.contact_mu, h, fe, Ag[i]);
+            f[i].a = f[i].a - fe.a;
+            f[i].l = f[i].l - fe.l;
+        }
         Ep = E; pp = p; vp = v; ap = a;
     }
     // backward pass: composite inertias (mass-matrix columns) and bias torques
@@ -817,10 +830,10 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         if constexpr (BAKED) {
             // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
             Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<true, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+            leg_pass<true, true, LOWREG>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         } else {
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<false, false>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+            leg_pass<false, false, LOWREG>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
@@ -848,12 +861,18 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
                 }
             }
             wsum = quad_sum(wsum);
-            s = quad_sum(s);
-            Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-            SV fe;
-            contact_finish(wsum, s, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
-            p0.a = p0.a - fe.a;
-            p0.l = p0.l - fe.l;
+            // Wave-uniform skip: under actuation the robot stands on its feet and the FRAME practically never touches the
+            // floor; when no env of the wave has a FRAME sample point below the margin every term below is exactly zero.
+            // (A/B on one box: +3.4 % at 4096 envs, +6.5 % at 262 144.  The same skip per leg link does NOT pay: a taken
+            // branch over a large block stalls the instruction fetch of a wave that is alone on its SIMD.)
+            if (__any(wsum > 0.f)) {
+                s = quad_sum(s);
+                Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+                SV fe;
+                contact_finish(wsum, s, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
+                p0.a = p0.a - fe.a;
+                p0.l = p0.l - fe.l;
+            }
         }
         add(Ic0, Ic);
         SV b = {v3(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a, v3(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l};
