@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--generic-model", action="store_true", help="perturb one mass by 1e-3 so the table-driven (generic) kernel variant runs")
     ap.add_argument("--force-gather", action="store_true", help="run the per-step gather even with one rank (measures its host-side cost)")
     ap.add_argument("--gather-op", choices=["gather", "all_gather"], default="gather", help="collective used for the per-step exchange")
+    ap.add_argument("--graph", type=int, default=0, metavar="G",
+                    help="capture G env-steps (kernel + per-step collective, double-buffered) into one hipGraph and replay it; "
+                         "steps and warmup are rounded up to multiples of G.  Validated with a 1-rank RCCL group only: opt-in")
     ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
@@ -195,7 +198,7 @@ def main():
 
     step_fn = sim.bind_step_packed(pool, packed, stream=compute)
 
-    def run(k0, count):
+    def run_eager(k0, count):
         for k in range(k0, k0 + count):
             b = k & 1
             if gatherer is not None:
@@ -212,6 +215,49 @@ def main():
                 elif len(gatherer.pending) > 64:
                     del gatherer.pending[:-2]
 
+    graph = None
+    if args.graph > 0:
+        if walk is not None or args.rehearse_shared_gpu:
+            raise SystemExit("--graph serves the plain step (with or without the RCCL exchange)")
+        G = args.graph + (args.graph & 1)                # whole double-buffer cycles
+        args.steps = -(-args.steps // G) * G
+        args.warmup = -(-max(args.warmup, G) // G) * G
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(compute)
+        with torch.cuda.stream(side):                    # warm-up on the capture stream (lazy RCCL initialisation happens here)
+            warm = sim.bind_step_packed(pool, packed, stream=side)
+            for k in range(G):
+                if gatherer is not None:
+                    gatherer.wait_buffer_free(side)
+                warm(k & 15, k & 1)
+                if gatherer is not None:
+                    gatherer.submit(packed[k & 1])
+            if gatherer is not None:
+                gatherer.drain()
+        compute.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            cap = sim.bind_step_packed(pool, packed, stream=torch.cuda.current_stream(dev))
+            for k in range(G):
+                if gatherer is not None:
+                    gatherer.wait_buffer_free()          # becomes a dependency edge of the graph
+                cap(k & 15, k & 1)
+                if gatherer is not None:
+                    gatherer.submit(packed[k & 1])
+            if gatherer is not None:
+                for bb in (0, 1):                        # join the outstanding collectives before the graph ends
+                    if gatherer.work[bb] is not None:
+                        gatherer.work[bb].wait()
+                        gatherer.work[bb] = None
+                gatherer.pending.clear()
+
+    def run(k0, count):
+        if graph is None:
+            return run_eager(k0, count)
+        for _ in range(count // G):
+            graph.replay()
+
     def fence():
         if gatherer is not None:
             gatherer.drain()
@@ -224,9 +270,12 @@ def main():
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(compute)
+    tstream = compute if graph is None else side
+    if graph is not None:
+        torch.cuda.set_stream(side)
+    ev0.record(tstream)
     run(args.warmup, args.steps)
-    ev1.record(compute)
+    ev1.record(tstream)
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the stream the kernel runs on
@@ -262,6 +311,7 @@ def main():
                                    f"forward+control_cost+alive rewards, fall(z<0.05)+time-limit terminations, auto-reset, "
                                    f"obs={od} f32, U(-1,1) actions resident in HBM"
                                    + (", random yaw at reset" if args.random_yaw else "")
+                                   + (f", hipGraph of {args.graph} env-steps per replay" if args.graph > 0 else "")
                                    + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
                                    + (f", per-step RCCL {args.gather_op} of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if use_dist else ""),
                        "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name,

@@ -131,7 +131,8 @@ int64_t qg_time_limit_substeps(double timestep, double max_time);
 
 /* Replaces MjModel.from_xml_path + MjData (quadruped.py:59-60).  `env_index_base`
  * is the global index of this handle's env 0 (shards of one batch get disjoint
- * ranges so per-env random streams do not depend on the sharding). */
+ * ranges so per-env random streams do not depend on the sharding).  Random draws at reset come from a counter-based
+ * stream keyed by (seed, global env index, number of resets that env has gone through). */
 int qg_create(int32_t n_envs, int32_t device_id, const qg_model *model, const qg_task *task,
               uint64_t env_index_base, qg_sim **out);
 int qg_destroy(qg_sim *sim);

@@ -37,10 +37,10 @@ struct qg_sim {
     hipEvent_t ev0, ev1;
     uint64_t seed;
     uint64_t env_index_base;
-    uint64_t step_index;
     int32_t track_ctrl;
     int32_t baked;            // 1: the model equals the compiled-in default, the literal-constant kernel variant runs
     int32_t mapping;          // QG_MAP_AUTO / QG_MAP_LANE / QG_MAP_QUAD (request)
+    int32_t creating;
 };
 
 static thread_local char g_err[512] = "";
@@ -94,7 +94,7 @@ extern "C" int64_t qg_time_limit_substeps(double timestep, double max_time) { re
 extern "C" int qg_destroy(qg_sim *s) {
     if (!s) return QG_OK;
     (void)hipSetDevice(s->device);
-    void *ptrs[] = {s->d_model, s->d_task, s->st.qpos, s->st.qvel, s->st.act, s->st.ctrl, s->st.nstep, s->d_actions,
+    void *ptrs[] = {s->d_model, s->d_task, s->st.qpos, s->st.qvel, s->st.act, s->st.ctrl, s->st.nstep, s->st.episode, s->d_actions,
                     s->d_obs,   s->d_reward, s->d_comps, s->d_stage, s->d_done, s->d_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -156,6 +156,7 @@ extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *mode
     ALLOC(s->st.act, n * QG_NU * sizeof(float));
     ALLOC(s->st.ctrl, n * QG_NU * sizeof(float));
     ALLOC(s->st.nstep, n * sizeof(int32_t));
+    ALLOC(s->st.episode, n * sizeof(int32_t));
     ALLOC(s->d_actions, n * QG_NU * sizeof(float));
     ALLOC(s->d_obs, n * (QG_NSENSOR + 2) * sizeof(float));
     ALLOC(s->d_reward, n * sizeof(float));
@@ -173,8 +174,14 @@ extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *mode
         qg_destroy(s);
         return fail(QG_ERR_DEVICE, "device setup: %s", hipGetErrorString(e));
     }
+    if (hipMemset(s->st.episode, 0, n * sizeof(int32_t)) != hipSuccess) {
+        qg_destroy(s);
+        return fail(QG_ERR_DEVICE, "device setup: memset");
+    }
     *out = s;
+    s->creating = 1;                 // the constructor's own reset does not count as an episode
     rc = qg_reset(s, nullptr, 0, 0);
+    s->creating = 0;
     if (rc != QG_OK) {
         qg_destroy(s);
         *out = nullptr;
@@ -196,7 +203,7 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
     }
     int threads = 256, blocks = (s->n + threads - 1) / threads;
     hipLaunchKernelGGL(qg_reset_kernel, dim3(blocks), dim3(threads), 0, s->stream, s->d_model, s->d_task, s->st, s->n, dmask, seed,
-                       s->env_index_base, s->step_index, flags);
+                       s->env_index_base, flags, s->creating ? 0 : 1);
     HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
     HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
     return QG_OK;
@@ -225,7 +232,6 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.packed = d_packed;
     P.seed = s->seed;
     P.env_index_base = s->env_index_base;
-    P.step_index = s->step_index;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     if (effective_mapping(s) == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
@@ -241,7 +247,6 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
     else
         hipLaunchKernelGGL(qg_step_kernel<false>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-    s->step_index++;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_step_kernel launch: %s", hipGetErrorString(e));
     return QG_OK;

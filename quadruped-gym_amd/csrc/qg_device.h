@@ -59,6 +59,7 @@ struct KState {
     float *act;       // [12][n]
     float *ctrl;      // [12][n]  last env-clipped action (data.ctrl); written only when track_ctrl
     int32_t *nstep;   // [n]
+    int32_t *episode; // [n]   resets this env has gone through: the counter of its reset random stream (graph-replay safe)
 };
 
 struct KStepArgs {
@@ -73,5 +74,4 @@ struct KStepArgs {
     float *packed;            // [n][obs_dim+2] or NULL
     uint64_t seed;            // reset stream
     uint64_t env_index_base;
-    uint64_t step_index;      // counter for the reset stream
 };

@@ -741,7 +741,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
         B.pw = v3(M->qpos0[0], M->qpos0[1], M->qpos0[2]);
         B.qw = M->qpos0[3]; B.qx = M->qpos0[4]; B.qy = M->qpos0[5]; B.qz = M->qpos0[6];
         if (T->reset_flags & 1u) {   // random heading (walking_quad.py:68-75)
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, P.step_index);
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
             B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
@@ -756,6 +756,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
         P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
         P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
         P.st.nstep[env] = nstep;
+        if (rst) P.st.episode[env] += 1;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             P.st.qpos[(7 + j) * n + env] = rst ? M->qpos0[7 + j] : lds[LQ(j) * 64 + lane];
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
         B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
         if (T->reset_flags & 1u) {
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, P.step_index);
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
             B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
@@ -1027,6 +1028,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
         P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
         P.st.nstep[env] = nstep;
+        if (rst) P.st.episode[env] += 1;
     }
     if (live) {
 #pragma unroll
@@ -1044,13 +1046,13 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
 // reset (quadruped.py:115-139): mj_resetData, time = 0, ctrl = default; optional random yaw
 // ------------------------------------------------------------------------------------------
 __global__ void qg_reset_kernel(const KModel *__restrict__ M, const KTask *__restrict__ T, KState st, int n, const uint8_t *mask,
-                                uint64_t seed, uint64_t env_index_base, uint64_t counter, uint32_t flags) {
+                                uint64_t seed, uint64_t env_index_base, uint32_t flags, int count_episode) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= n) return;
     if (mask && !mask[env]) return;
     for (int j = 0; j < 19; ++j) st.qpos[j * n + env] = M->qpos0[j];
     if (flags & 1u) {
-        float a = 6.283185307179586f * uniform24(seed, env_index_base + (uint64_t)env, counter);
+        float a = 6.283185307179586f * uniform24(seed, env_index_base + (uint64_t)env, (uint64_t)st.episode[env]);
         float sn, cs;
         sincos_f(0.5f * a, sn, cs);
         st.qpos[3 * n + env] = cs; st.qpos[4 * n + env] = 0.f; st.qpos[5 * n + env] = 0.f; st.qpos[6 * n + env] = sn;
@@ -1058,6 +1060,7 @@ __global__ void qg_reset_kernel(const KModel *__restrict__ M, const KTask *__res
     for (int j = 0; j < 18; ++j) st.qvel[j * n + env] = 0.f;
     for (int j = 0; j < 12; ++j) { st.act[j * n + env] = 0.f; st.ctrl[j * n + env] = T->default_ctrl[j]; }
     st.nstep[env] = 0;
+    if (count_episode) st.episode[env] += 1;
 }
 
 // env-major [n][w] <-> field-major [w][n] (state snapshot / restore at the ABI)
