@@ -341,12 +341,15 @@ def compile_mjcf(scene_path, mesh_inertia="convex"):
             cps = select_contact_points(cloud[hv], CP_FRAME, fold=4)
             # exact 4-fold orbits (3 base points x 4 quarter turns, stored orbit-major): the mesh is symmetric
             # only to its 1e-6 vertex resolution; the one-leg-per-lane kernel rotates the base points itself
-            base_pts = cps[[0, 4, 8]]
+            orbits = max(1, len(cps) // 4)
+            base_pts = [cps[4 * (o % orbits)] for o in range(CP_FRAME // 4)]     # a hull with few vertices repeats its orbits
             quarter = [np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1.0]]), np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]]),
                        np.array([[-1, 0, 0], [0, -1, 0], [0, 0, 1.0]]), np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])]
             cps = np.array([R @ bp for bp in base_pts for R in quarter])
         else:
             cps = select_contact_points(cloud[hv], CP_LINK)
+            if len(cps) < CP_LINK:                       # the kernels carry exactly CP_LINK points per link: repeat cyclically
+                cps = np.array([cps[i % len(cps)] for i in range(CP_LINK)])
         out_bodies.append(dict(name=b["name"], parent=b["parent"], pos=b["pos"], quat=b["quat"], mass=mass,
                                ipos=ipos, inertia=inertia, contact_points=cps,
                                friction=max(g["friction"] for g in b["geoms"]),
