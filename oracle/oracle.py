@@ -90,8 +90,14 @@ def _arr(x, n):
     return a
 
 
+_limit_cache = {}
+
+
 def time_limit_substeps(timestep, max_time) -> int:
-    return int(lib().qgo_time_limit_substeps(timestep, max_time))
+    key = (float(timestep), float(max_time))
+    if key not in _limit_cache:
+        _limit_cache[key] = int(lib().qgo_time_limit_substeps(timestep, max_time))
+    return _limit_cache[key]
 
 
 def uniform(seed, env_index, counter) -> float:

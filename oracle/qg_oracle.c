@@ -545,6 +545,7 @@ int qgo_reset(const qg_model *m, const qg_task *t, qgo_env *e, uint64_t seed, ui
 }
 
 int64_t qgo_time_limit_substeps(double timestep, double max_time) {
+    if (!(max_time / timestep < 2.0e9)) return 2147483647;   /* beyond the int32 substep counter: never reached */
     double t = 0;
     int64_t n = 0;
     while (!(t >= max_time)) {   /* quadruped.py:151 `data.time >= max_time`, f64 accumulation */

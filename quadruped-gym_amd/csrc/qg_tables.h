@@ -16,6 +16,7 @@ int qg_fail(int code, const char *fmt, ...);   // records the message for qg_las
 
 static inline int64_t qg_time_limit_substeps_impl(double timestep, double max_time) {
     if (!(timestep > 0)) return -1;
+    if (!(max_time / timestep < 2.0e9)) return INT32_MAX;    // beyond the int32 substep counter: never reached
     double t = 0;
     int64_t n = 0;
     while (!(t >= max_time)) {     // quadruped.py:151 with the engine's `time += timestep` (f64)

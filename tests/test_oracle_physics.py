@@ -33,6 +33,7 @@ def test_time_limit_matches_f64_accumulation(oracle):
         assert oracle.time_limit_substeps(h, tmax) == n
     assert oracle.time_limit_substeps(0.002, 10.0) == 5000
     assert oracle.time_limit_substeps(0.002, 20.0) == 10001   # accumulation lands just below 20.0 at 10000
+    assert oracle.time_limit_substeps(0.002, 1e9) == 2 ** 31 - 1   # effectively no limit: answered without looping
 
 
 def test_mass_matrix_spd_and_kinetic_energy(oracle, model):
