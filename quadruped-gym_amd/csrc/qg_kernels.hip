@@ -5,25 +5,29 @@
 // implicitfast, quadruped.xml:4), the sensor pack (quadruped.py:141-143, quadruped.xml:174-217),
 // the README reward / termination set (README.md:64-90) and reset (quadruped.py:115-139).
 //
-// Mapping: ONE ENVIRONMENT PER WAVEFRONT LANE, one 64-lane wave per workgroup.  State is
-// struct-of-arrays in HBM ([field][env]) so every load/store of a wave is one 256-byte
-// segment.  All frame_skip substeps run inside one launch; state is read once and written
-// once per env-step.  No MFMA: the path is a chain of small (3x3 / 6x6) per-env solves.
+// Two work mappings of the same physics (shared device functions below):
+//   qg_step_kernel       ONE ENVIRONMENT PER WAVEFRONT LANE, 64 envs per wave; the legs are a rolled loop, the joint
+//                        state and the per-leg factors live in per-lane LDS columns (they are indexed by the run-time
+//                        leg index);
+//   qg_step_kernel_quad  ONE LEG PER LANE, four lanes per environment, 16 envs per wave; leg terms are reduced over
+//                        the quad with DPP adds, everything stays in registers.  ~3.5x fewer instructions per wave,
+//                        which is what sets the time of an env-step at batch sizes that leave most SIMDs idle.
+// State is struct-of-arrays in HBM ([field][env]) so a wave's loads and stores of a field are contiguous.  All frame_skip
+// substeps run inside one launch; state is read once and written once per env-step.  No MFMA: the path is a chain of
+// small (3x3 / 6x6) per-env solves, bound by VALU issue, not by HBM.
+// Constants: BAKED variants read the compiled-in robot from a const table with compile-time indices (instruction
+// literals); generic variants read any model numbers from device memory (scalar loads / an LDS copy).
 //
-// Formulation (different on purpose from the CPU oracle, which works in world coordinates
-// with a dense 18x18 solve): everything is expressed in the FRAME's own axes about the
-// FRAME's origin.  Per substep
-//   A. base prelude: rotation from the quaternion, base velocity / bias acceleration,
-//      FRAME body force and ground contact, start of the base 6x6 block;
-//   B. loop over the 4 legs (rolled): kinematics of fema/shin/foot, recursive Newton-Euler
-//      bias forces, ground contact, composite-rigid-body inertia (mass matrix columns), servo
-//      / limit / damping terms, then block elimination of the leg's 3x3 joint block into the
-//      base block (the mass matrix is base 6x6 + four 3x3 leg blocks + four 6x3 couplings);
-//      the per-leg factors (Y = F H^-1, u = H^-1 b) and the joint state live in LDS, one
-//      column per lane, because the leg loop indexes them at run time;
+// Formulation (different on purpose from the CPU oracle, which works in world coordinates with a dense 18x18 solve):
+// everything is expressed in the FRAME's own axes about the FRAME's origin.  Per substep
+//   A. base prelude: rotation from the quaternion, base velocity / bias acceleration, FRAME body force and ground
+//      contact, start of the base 6x6 block;
+//   B. per leg (leg_pass): kinematics of fema/shin/foot, recursive Newton-Euler bias forces, ground contact,
+//      composite-rigid-body inertia (mass matrix columns), servo / limit / damping terms, then block elimination of the
+//      leg's 3x3 joint block into the base block (leg_eliminate) -- the mass matrix is base 6x6 + four 3x3 leg blocks +
+//      four 6x3 couplings and is never formed densely;
 //   C. 6x6 base solve (LDL^T);
-//   D. loop over the legs: back-substitution, semi-implicit integration of the hinges,
-//      servo activation filter;
+//   D. back-substitution, semi-implicit integration of the hinges, servo activation filter;
 //   E. base integration (position, quaternion).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
