@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--generic-model", action="store_true", help="perturb one mass by 1e-3 so the table-driven (generic) kernel variant runs")
     ap.add_argument("--force-gather", action="store_true", help="run the per-step gather even with one rank (measures its host-side cost)")
     ap.add_argument("--gather-op", choices=["gather", "all_gather"], default="gather", help="collective used for the per-step exchange")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="issue the per-step gather from the library's C loop over RCCL (qg_comm_*) instead of torch.distributed; "
+                         "validated with a 1-rank communicator only: opt-in")
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G env-steps (kernel + per-step collective, double-buffered) into one hipGraph and replay it; "
                          "steps and warmup are rounded up to multiples of G.  Validated with a 1-rank RCCL group only: opt-in")
@@ -144,7 +147,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_gather
+    use_dist = world > 1 or (args.force_gather and not args.native_rccl)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -179,7 +182,26 @@ def main():
     packed = [torch.empty((n, row), device=dev) for _ in range(2)]
     compute = torch.cuda.current_stream(dev)
     gatherer = None
-    if use_dist:
+    native = None
+    if args.native_rccl:
+        import ctypes as C
+        from quadruped_gym_amd._abi import check
+        lib = _abi.load_library()
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            check(lib.qg_comm_unique_id(uid), "qg_comm_unique_id")
+        if world > 1:                                   # hand the id to the other ranks through torch.distributed
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0)
+            for i, v in enumerate(t.cpu().tolist()):
+                uid[i] = v
+        native = C.c_void_p()
+        check(lib.qg_comm_create(sim._h, rank, world, uid, C.byref(native)), "qg_comm_create")
+        n_gath = [torch.empty((world, n, row), device=dev) for _ in range(2)] if rank == 0 else None
+        a_arr = (C.c_void_p * len(pool))(*[p.data_ptr() for p in pool])
+        p_arr = (C.c_void_p * 2)(packed[0].data_ptr(), packed[1].data_ptr())
+        g_arr = (C.c_void_p * 2)(n_gath[0].data_ptr(), n_gath[1].data_ptr()) if rank == 0 else None
+    elif use_dist:
         from quadruped_gym_amd.dist import PackedGatherer
         gatherer = PackedGatherer(n, row, "cpu" if args.rehearse_shared_gpu else dev, dst=0, op=args.gather_op)
 
@@ -253,12 +275,17 @@ def main():
                 gatherer.pending.clear()
 
     def run(k0, count):
+        if native is not None:
+            check(lib.qg_comm_rollout(native, a_arr, len(pool), p_arr, g_arr, count, 0), "qg_comm_rollout")
+            return
         if graph is None:
             return run_eager(k0, count)
         for _ in range(count // G):
             graph.replay()
 
     def fence():
+        if native is not None:
+            check(lib.qg_comm_synchronize(native), "qg_comm_synchronize")
         if gatherer is not None:
             gatherer.drain()
         torch.cuda.synchronize(dev)
@@ -279,6 +306,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the stream the kernel runs on
+    if native is not None:
+        kernel_ms = dt / args.steps * 1e3                # the C loop runs on the library's own streams: wall clock per step
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -313,7 +342,8 @@ def main():
                                    + (", random yaw at reset" if args.random_yaw else "")
                                    + (f", hipGraph of {args.graph} env-steps per replay" if args.graph > 0 else "")
                                    + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
-                                   + (f", per-step RCCL {args.gather_op} of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if use_dist else ""),
+                                   + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 from the library's C loop (qg_comm_rollout, overlapped)" if native is not None else
+                                      (f", per-step RCCL {args.gather_op} of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if use_dist else "")),
                        "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name,
                        "constants": "baked literals" if sim.baked else "tables (LDS / scalar loads)"},
             "substeps_per_sec": value * args.frame_skip,
@@ -334,6 +364,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)
         print(json.dumps(line), flush=True)
+    if native is not None:
+        lib.qg_comm_destroy(native)
     sim.close()
     if use_dist:
         dist.barrier()

@@ -182,6 +182,25 @@ int qg_uses_baked_model(const qg_sim *sim);
 int qg_set_mapping(qg_sim *sim, int32_t mapping);
 int qg_get_mapping(const qg_sim *sim);
 
+/* ---- native per-step exchange over RCCL (opt-in) --------------------------------------------------------------
+ * Env batches shard across the GPUs of a node, one process per GPU, no exchange inside the physics; once per env-step
+ * the packed [n_envs][obs_dim + 2] rows are gathered to `root` over xGMI.  These entry points issue that gather from C
+ * (RCCL loaded with dlopen, no link-time dependency) so that the host cost per step is a few microseconds instead of
+ * torch.distributed's ~30; the unique id is created on one rank and handed to the others by whatever channel the
+ * caller has (bench.py broadcasts it through torch.distributed).  Validated with a 1-rank communicator only so far. */
+#define QG_COMM_ID_BYTES 128
+typedef struct qg_comm qg_comm;
+int qg_comm_unique_id(uint8_t id[QG_COMM_ID_BYTES]);
+int qg_comm_create(qg_sim *sim, int32_t rank, int32_t world, const uint8_t id[QG_COMM_ID_BYTES], qg_comm **out);
+int qg_comm_destroy(qg_comm *comm);
+/* `steps` env-steps with one gather each, double-buffered and overlapped: step k reads actions[k % n_actions] (device
+ * pointers, host array of n_actions pointers), writes packed[k & 1] and gathers it into gathered[k & 1]
+ * ([world][n_envs][obs_dim + 2] on the root; ignored elsewhere).  Returns when everything is enqueued. */
+int qg_comm_rollout(qg_comm *comm, const float *const *actions, int32_t n_actions, float *const packed[2],
+                    float *const gathered[2], int32_t steps, int32_t root);
+/* Block the host until the communicator's streams are idle. */
+int qg_comm_synchronize(qg_comm *comm);
+
 /* ---- walking task layer ----------------------------------------------
  * What WalkingQuadrupedEnv adds around QuadrupedEnv.step() (src/envs/walking_quad.py): the velocity /
  * heading command (src/envs/control_inputs.py), the settling-time action mask (:142-143), the online

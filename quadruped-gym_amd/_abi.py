@@ -146,6 +146,11 @@ def load_library():
     lib.qg_uses_baked_model.argtypes = [vp]
     lib.qg_set_mapping.argtypes = [vp, C.c_int32]
     lib.qg_get_mapping.argtypes = [vp]
+    lib.qg_comm_unique_id.argtypes = [vp]
+    lib.qg_comm_create.argtypes = [vp, C.c_int32, C.c_int32, vp, C.POINTER(vp)]
+    lib.qg_comm_destroy.argtypes = [vp]
+    lib.qg_comm_rollout.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int32, C.c_int32]
+    lib.qg_comm_synchronize.argtypes = [vp]
     lib.qg_walk_default_params.argtypes = [C.POINTER(QgWalkParams)]
     lib.qg_walk_create.argtypes = [vp, C.POINTER(QgWalkParams), C.POINTER(vp)]
     lib.qg_walk_destroy.argtypes = [vp]
@@ -173,6 +178,7 @@ EXPORTS = (
     "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
     "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
+    "qg_comm_unique_id", "qg_comm_create", "qg_comm_destroy", "qg_comm_rollout", "qg_comm_synchronize",
     "qg_walk_default_params", "qg_walk_create", "qg_walk_destroy", "qg_walk_set_commands", "qg_walk_reset", "qg_walk_step",
     "qg_walk_step_device", "qg_walk_get_estimates",
     "qg_po_create", "qg_po_destroy", "qg_po_obs_dim", "qg_po_reset", "qg_po_step", "qg_po_step_device",

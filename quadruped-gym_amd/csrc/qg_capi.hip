@@ -364,6 +364,103 @@ extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// native per-step exchange over RCCL (qg_comm.h)
+// ------------------------------------------------------------------------------------------------------
+#include "qg_comm.h"
+
+extern "C" int qg_comm_unique_id(uint8_t id[QG_COMM_ID_BYTES]) {
+    if (!id) return fail(QG_ERR_ARG, "qg_comm_unique_id: null output");
+    int rc = qg_rccl_load();
+    if (rc != QG_OK) return rc;
+    qg_nccl_unique_id u;
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, QG_COMM_ID_BYTES);
+    return QG_OK;
+}
+
+extern "C" int qg_comm_destroy(qg_comm *c) {
+    if (!c) return QG_OK;
+    (void)hipSetDevice(c->sim->device);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    for (int i = 0; i < 2; i++) {
+        if (c->produced[i]) (void)hipEventDestroy(c->produced[i]);
+        if (c->consumed[i]) (void)hipEventDestroy(c->consumed[i]);
+    }
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    delete c;
+    return QG_OK;
+}
+
+extern "C" int qg_comm_create(qg_sim *s, int32_t rank, int32_t world, const uint8_t id[QG_COMM_ID_BYTES], qg_comm **out) {
+    if (!s || !id || !out || world < 1 || rank < 0 || rank >= world) return fail(QG_ERR_ARG, "qg_comm_create: bad argument");
+    *out = nullptr;
+    int rc = qg_rccl_load();
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    qg_comm *c = new (std::nothrow) qg_comm();
+    if (!c) return fail(QG_ERR_ALLOC, "out of host memory");
+    memset(c, 0, sizeof *c);
+    c->sim = s;
+    c->rank = rank;
+    c->world = world;
+    hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->produced[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->consumed[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        qg_comm_destroy(c);
+        return fail(QG_ERR_DEVICE, "qg_comm_create: %s", hipGetErrorString(e));
+    }
+    qg_nccl_unique_id u;
+    memcpy(u.internal, id, QG_COMM_ID_BYTES);
+    int r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != 0) {
+        const char *msg = g_rccl.GetErrorString(r);
+        qg_comm_destroy(c);
+        return fail(QG_ERR_DEVICE, "ncclCommInitRank: %s", msg);
+    }
+    *out = c;
+    return QG_OK;
+}
+
+extern "C" int qg_comm_rollout(qg_comm *c, const float *const *actions, int32_t n_actions, float *const packed[2], float *const gathered[2],
+                               int32_t steps, int32_t root) {
+    if (!c || !actions || n_actions < 1 || !packed || steps < 0 || root < 0 || root >= c->world) return fail(QG_ERR_ARG, "qg_comm_rollout: bad argument");
+    if (c->rank == root && !gathered) return fail(QG_ERR_ARG, "qg_comm_rollout: the root needs the gathered buffers");
+    qg_sim *s = c->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    const size_t count = (size_t)s->n * (size_t)(s->obs_dim + 2);
+    for (int k = 0; k < steps; k++) {
+        const int b = k & 1;
+        // the step may overwrite packed[b] only after the gather that read it (two steps ago) has finished
+        if (c->consumed_valid[b]) HIP_TRY(hipStreamWaitEvent(s->stream, c->consumed[b], 0), QG_ERR_DEVICE);
+        int rc = launch_step(s, actions[k % n_actions], nullptr, nullptr, nullptr, nullptr, packed[b], s->stream);
+        if (rc != QG_OK) return rc;
+        HIP_TRY(hipEventRecord(c->produced[b], s->stream), QG_ERR_DEVICE);
+        HIP_TRY(hipStreamWaitEvent(c->comm_stream, c->produced[b], 0), QG_ERR_DEVICE);
+        RCCL_TRY(g_rccl.GroupStart());
+        if (c->rank == root)
+            for (int r = 0; r < c->world; r++)
+                RCCL_TRY(g_rccl.Recv(gathered[b] + (size_t)r * count, count, QG_NCCL_FLOAT32, r, c->comm, c->comm_stream));
+        RCCL_TRY(g_rccl.Send(packed[b], count, QG_NCCL_FLOAT32, root, c->comm, c->comm_stream));
+        RCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(hipEventRecord(c->consumed[b], c->comm_stream), QG_ERR_DEVICE);
+        c->consumed_valid[b] = 1;
+    }
+    return QG_OK;
+}
+
+extern "C" int qg_comm_synchronize(qg_comm *c) {
+    if (!c) return fail(QG_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(c->sim->device), QG_ERR_DEVICE);
+    HIP_TRY(hipStreamSynchronize(c->sim->stream), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(c->comm_stream), QG_ERR_LAUNCH);
+    return QG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // walking task layer (qg_walk.hip)
 // ------------------------------------------------------------------------------------------------------
 struct qg_walk {
