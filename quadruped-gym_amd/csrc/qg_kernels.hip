@@ -52,83 +52,133 @@ template <bool BAKED> DEV const KModel &table(const KModel *__restrict__ M) {
 template <bool BAKED> DEV const KLink &link_of(const KModel &C, int k, int i) { return C.link[BAKED ? i : 3 * k + i]; }
 
 // ------------------------------------------------------------------------------------------
+// scalar layer.  Every physics function below is a template on the scalar type T:
+//   T = float  one leg (or one env) per lane -- the lane and quad kernels;
+//   T = f2     a 2-wide ext-vector: TWO LEGS per lane.  hipcc turns fma / mul / add on f2 into v_pk_fma_f32 /
+//              v_pk_mul_f32 / v_pk_add_f32 -- two legs for the issue slot of one, with no shuffles because every
+//              quantity of the pair lives in an aligned register pair from the start (measured: identical instruction
+//              count to the float build of the same code, all packed, zero v_mov).  max / min / select / rcp / sqrt /
+//              compares have no packed f32 form on gfx950 and run once per component.
+// Conditionals are written as masks + select so that the same source serves both.
+// ------------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+DEV float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+DEV f2 fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEV float max_(float a, float b) { return fmaxf(a, b); }
+DEV f2 max_(f2 a, f2 b) { f2 r = {fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; return r; }
+DEV float min_(float a, float b) { return fminf(a, b); }
+DEV f2 min_(f2 a, f2 b) { f2 r = {fminf(a.x, b.x), fminf(a.y, b.y)}; return r; }
+DEV float abs_(float a) { return fabsf(a); }
+DEV f2 abs_(f2 a) { f2 r = {fabsf(a.x), fabsf(a.y)}; return r; }
+DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV f2 rcp(f2 x) { f2 r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; return r; }
+DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+DEV f2 sqrt_(f2 x) { f2 r = {__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; return r; }
+// masks: bool for float, i2 (-1 / 0 per component, what a vector compare yields) for f2
+DEV float sel(bool m, float a, float b) { return m ? a : b; }
+DEV f2 sel(i2 m, f2 a, f2 b) { f2 r = {m.x ? a.x : b.x, m.y ? a.y : b.y}; return r; }
+DEV bool m_and(bool a, bool b) { return a && b; }
+DEV i2 m_and(i2 a, i2 b) { return a & b; }
+DEV bool m_or(bool a, bool b) { return a || b; }
+DEV i2 m_or(i2 a, i2 b) { return a | b; }
+DEV bool m_not(bool a) { return !a; }
+DEV i2 m_not(i2 a) { return ~a; }
+DEV bool m_any(bool a) { return a; }
+DEV bool m_any(i2 a) { return (a.x | a.y) != 0; }
+template <class T> DEV T splat(float x) { return T(x); }
+
+// ------------------------------------------------------------------------------------------
 // small fixed-size algebra
 // ------------------------------------------------------------------------------------------
-struct V3 { float x, y, z; };
-DEV V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
-DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
-DEV float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
-DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-DEV V3 fma3(float s, V3 a, V3 b) { return v3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
-DEV V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
+template <class T> struct V3T { T x, y, z; };
+typedef V3T<float> V3;
+template <class T> DEV V3T<T> v3(T x, T y, T z) { V3T<T> r = {x, y, z}; return r; }
+template <class T> DEV V3T<T> operator+(V3T<T> a, V3T<T> b) { return v3<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <class T> DEV V3T<T> operator-(V3T<T> a, V3T<T> b) { return v3<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <class T> DEV V3T<T> operator*(T s, V3T<T> a) { return v3<T>(s * a.x, s * a.y, s * a.z); }
+template <class T> DEV T dot(V3T<T> a, V3T<T> b) { return fma_(a.x, b.x, fma_(a.y, b.y, a.z * b.z)); }
+template <class T> DEV V3T<T> cross(V3T<T> a, V3T<T> b) { return v3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+template <class T> DEV V3T<T> fma3(T s, V3T<T> a, V3T<T> b) { return v3<T>(fma_(s, a.x, b.x), fma_(s, a.y, b.y), fma_(s, a.z, b.z)); }
+DEV V3 ld3(const float *p) { return v3<float>(p[0], p[1], p[2]); }
+template <class T> DEV V3T<T> ld3t(const float *p) { return v3<T>(T(p[0]), T(p[1]), T(p[2])); }     // a model constant, same for every component
+template <class T> DEV V3T<T> splat3(V3 a) { return v3<T>(T(a.x), T(a.y), T(a.z)); }
 
 // orthonormal frame given by its three axes (columns) expressed in the working frame
-struct Fr { V3 ex, ey, ez; };
-DEV V3 rot(const Fr &E, V3 r) { return fma3(r.x, E.ex, fma3(r.y, E.ey, r.z * E.ez)); }   // local -> working
-DEV V3 rotT(const Fr &E, V3 r) { return v3(dot(E.ex, r), dot(E.ey, r), dot(E.ez, r)); }  // working -> local
+template <class T> struct FrT { V3T<T> ex, ey, ez; };
+typedef FrT<float> Fr;
+template <class T> DEV V3T<T> rot(const FrT<T> &E, V3T<T> r) { return fma3(r.x, E.ex, fma3(r.y, E.ey, r.z * E.ez)); }   // local -> working
+template <class T> DEV V3T<T> rotT(const FrT<T> &E, V3T<T> r) { return v3<T>(dot(E.ex, r), dot(E.ey, r), dot(E.ez, r)); }  // working -> local
 
-struct Sym3 { float xx, yy, zz, xy, xz, yz; };
-DEV V3 mul(const Sym3 &S, V3 v) {
-    return v3(fmaf(S.xx, v.x, fmaf(S.xy, v.y, S.xz * v.z)), fmaf(S.xy, v.x, fmaf(S.yy, v.y, S.yz * v.z)),
-              fmaf(S.xz, v.x, fmaf(S.yz, v.y, S.zz * v.z)));
+template <class T> struct Sym3T { T xx, yy, zz, xy, xz, yz; };
+typedef Sym3T<float> Sym3;
+template <class T> DEV V3T<T> mul(const Sym3T<T> &S, V3T<T> v) {
+    return v3<T>(fma_(S.xx, v.x, fma_(S.xy, v.y, S.xz * v.z)), fma_(S.xy, v.x, fma_(S.yy, v.y, S.yz * v.z)),
+                 fma_(S.xz, v.x, fma_(S.yz, v.y, S.zz * v.z)));
 }
-DEV void add(Sym3 &a, const Sym3 &b) { a.xx += b.xx; a.yy += b.yy; a.zz += b.zz; a.xy += b.xy; a.xz += b.xz; a.yz += b.yz; }
-DEV void rank1(Sym3 &a, float w, V3 u, V3 v) {  // a += w * (u v^T), caller guarantees symmetry (u == v)
-    a.xx = fmaf(w * u.x, v.x, a.xx); a.yy = fmaf(w * u.y, v.y, a.yy); a.zz = fmaf(w * u.z, v.z, a.zz);
-    a.xy = fmaf(w * u.x, v.y, a.xy); a.xz = fmaf(w * u.x, v.z, a.xz); a.yz = fmaf(w * u.y, v.z, a.yz);
+template <class T> DEV void add(Sym3T<T> &a, const Sym3T<T> &b) { a.xx += b.xx; a.yy += b.yy; a.zz += b.zz; a.xy += b.xy; a.xz += b.xz; a.yz += b.yz; }
+template <class T> DEV void rank1(Sym3T<T> &a, T w, V3T<T> u, V3T<T> v) {  // a += w * (u v^T), caller guarantees symmetry (u == v)
+    a.xx = fma_(w * u.x, v.x, a.xx); a.yy = fma_(w * u.y, v.y, a.yy); a.zz = fma_(w * u.z, v.z, a.zz);
+    a.xy = fma_(w * u.x, v.y, a.xy); a.xz = fma_(w * u.x, v.z, a.xz); a.yz = fma_(w * u.y, v.z, a.yz);
 }
 
-struct M3 { V3 r0, r1, r2; };  // rows
-DEV V3 mul(const M3 &A, V3 v) { return v3(dot(A.r0, v), dot(A.r1, v), dot(A.r2, v)); }
-DEV V3 mulT(const M3 &A, V3 v) { return fma3(v.x, A.r0, fma3(v.y, A.r1, v.z * A.r2)); }
-DEV void add(M3 &a, const M3 &b) { a.r0 = a.r0 + b.r0; a.r1 = a.r1 + b.r1; a.r2 = a.r2 + b.r2; }
+template <class T> struct M3T { V3T<T> r0, r1, r2; };  // rows
+typedef M3T<float> M3;
+template <class T> DEV V3T<T> mul(const M3T<T> &A, V3T<T> v) { return v3<T>(dot(A.r0, v), dot(A.r1, v), dot(A.r2, v)); }
+template <class T> DEV V3T<T> mulT(const M3T<T> &A, V3T<T> v) { return fma3(v.x, A.r0, fma3(v.y, A.r1, v.z * A.r2)); }
+template <class T> DEV void add(M3T<T> &a, const M3T<T> &b) { a.r0 = a.r0 + b.r0; a.r1 = a.r1 + b.r1; a.r2 = a.r2 + b.r2; }
 
 // spatial vectors [angular; linear] about the FRAME origin, FRAME axes
-struct SV { V3 a, l; };
-DEV SV operator+(SV p, SV q) { SV r = {p.a + q.a, p.l + q.l}; return r; }
-DEV float dot(SV p, SV q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+template <class T> struct SVT { V3T<T> a, l; };
+typedef SVT<float> SV;
+template <class T> DEV SVT<T> operator+(SVT<T> p, SVT<T> q) { SVT<T> r = {p.a + q.a, p.l + q.l}; return r; }
+template <class T> DEV T dot(SVT<T> p, SVT<T> q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+template <class T> DEV SVT<T> splat6(SV v) { SVT<T> r = {splat3<T>(v.a), splat3<T>(v.l)}; return r; }
 
 // rigid-body spatial inertia about the FRAME origin: mass, first moment h = m*c, rotational inertia
-struct Rigid { float m; V3 h; Sym3 I; };
-DEV SV mul(const Rigid &B, SV v) {
-    SV f;
+template <class T> struct RigidT { T m; V3T<T> h; Sym3T<T> I; };
+typedef RigidT<float> Rigid;
+template <class T> DEV SVT<T> mul(const RigidT<T> &B, SVT<T> v) {
+    SVT<T> f;
     f.a = mul(B.I, v.a) + cross(B.h, v.l);
     f.l = B.m * v.l - cross(B.h, v.a);
     return f;
 }
 
 // general symmetric 6x6 (rigid inertia + implicit contact damping): [[AA, AL], [AL^T, LL]]
-struct Sym6 { Sym3 AA; M3 AL; Sym3 LL; };
-DEV SV mul(const Sym6 &A, SV s) {
-    SV f;
+template <class T> struct Sym6T { Sym3T<T> AA; M3T<T> AL; Sym3T<T> LL; };
+typedef Sym6T<float> Sym6;
+template <class T> DEV SVT<T> mul(const Sym6T<T> &A, SVT<T> s) {
+    SVT<T> f;
     f.a = mul(A.AA, s.a) + mul(A.AL, s.l);
     f.l = mulT(A.AL, s.a) + mul(A.LL, s.l);
     return f;
 }
-DEV void add(Sym6 &a, const Sym6 &b) { add(a.AA, b.AA); add(a.AL, b.AL); add(a.LL, b.LL); }
-DEV Sym6 sym6_of(const Rigid &B) {
-    Sym6 A;
+template <class T> DEV void add(Sym6T<T> &a, const Sym6T<T> &b) { add(a.AA, b.AA); add(a.AL, b.AL); add(a.LL, b.LL); }
+template <class T> DEV Sym6T<T> sym6_of(const RigidT<T> &B) {
+    Sym6T<T> A;
+    const T z = T(0.f);
     A.AA = B.I;
-    A.AL.r0 = v3(0.f, -B.h.z, B.h.y);   // [h]x
-    A.AL.r1 = v3(B.h.z, 0.f, -B.h.x);
-    A.AL.r2 = v3(-B.h.y, B.h.x, 0.f);
+    A.AL.r0 = v3<T>(z, -B.h.z, B.h.y);   // [h]x
+    A.AL.r1 = v3<T>(B.h.z, z, -B.h.x);
+    A.AL.r2 = v3<T>(-B.h.y, B.h.x, z);
     A.LL.xx = A.LL.yy = A.LL.zz = B.m;
-    A.LL.xy = A.LL.xz = A.LL.yz = 0.f;
+    A.LL.xy = A.LL.xz = A.LL.yz = z;
     return A;
 }
 // A += m * (point mass at r)  +  w * a a^T with a = [r x n; n]
-DEV void add_contact_damping(Sym6 &A, float m, float w, V3 r, V3 n) {
-    float rr = dot(r, r);
+template <class T> DEV void add_contact_damping(Sym6T<T> &A, T m, T w, V3T<T> r, V3T<T> n) {
+    T rr = dot(r, r);
     A.AA.xx += m * (rr - r.x * r.x); A.AA.yy += m * (rr - r.y * r.y); A.AA.zz += m * (rr - r.z * r.z);
     A.AA.xy -= m * r.x * r.y; A.AA.xz -= m * r.x * r.z; A.AA.yz -= m * r.y * r.z;
-    V3 h = m * r;
-    A.AL.r0 = A.AL.r0 + v3(0.f, -h.z, h.y);
-    A.AL.r1 = A.AL.r1 + v3(h.z, 0.f, -h.x);
-    A.AL.r2 = A.AL.r2 + v3(-h.y, h.x, 0.f);
+    V3T<T> h = m * r;
+    const T z = T(0.f);
+    A.AL.r0 = A.AL.r0 + v3<T>(z, -h.z, h.y);
+    A.AL.r1 = A.AL.r1 + v3<T>(h.z, z, -h.x);
+    A.AL.r2 = A.AL.r2 + v3<T>(-h.y, h.x, z);
     A.LL.xx += m; A.LL.yy += m; A.LL.zz += m;
-    V3 ra = cross(r, n);
+    V3T<T> ra = cross(r, n);
     rank1(A.AA, w, ra, ra);
     A.AL.r0 = fma3(w * ra.x, n, A.AL.r0);
     A.AL.r1 = fma3(w * ra.y, n, A.AL.r1);
@@ -136,23 +186,31 @@ DEV void add_contact_damping(Sym6 &A, float m, float w, V3 r, V3 n) {
     rank1(A.LL, w, n, n);
 }
 
-DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
 // sin and cos with Cody-Waite reduction to [-pi/4, pi/4] and minimax polynomials (~1 ulp for |x| < 1e4)
-DEV void sincos_f(float x, float &s, float &c) {
-    float k = rintf(x * 0.63661977236758134f);
-    float r = fmaf(-k, 1.57079625129699707031f, x);
-    r = fmaf(-k, 7.54978941586159635335e-08f, r);
-    float r2 = r * r;
-    float sp = fmaf(r2, fmaf(r2, fmaf(r2, 2.718311493989822e-06f, -1.984090162742e-04f), 8.333329385889463e-03f), -1.666666597127914e-01f);
-    float sr = fmaf(r * r2, sp, r);
-    float cp = fmaf(r2, fmaf(r2, fmaf(r2, 2.443315711809948e-05f, -1.388731625493765e-03f), 4.166664568298827e-02f), -0.5f);
-    float cr = fmaf(r2, cp, 1.0f);
+DEV void sincos_quadrant(float k, float sr, float cr, float &s, float &c) {
     int q = (int)k;
     float s0 = (q & 1) ? cr : sr;
     float c0 = (q & 1) ? sr : cr;
     s = (q & 2) ? -s0 : s0;
     c = ((q + 1) & 2) ? -c0 : c0;
+}
+DEV float rint_(float x) { return rintf(x); }
+DEV f2 rint_(f2 x) { f2 r = {rintf(x.x), rintf(x.y)}; return r; }
+template <class T> DEV void sincos_f(T x, T &s, T &c) {
+    T k = rint_(x * 0.63661977236758134f);
+    T r = fma_(-k, T(1.57079625129699707031f), x);
+    r = fma_(-k, T(7.54978941586159635335e-08f), r);
+    T r2 = r * r;
+    T sp = fma_(r2, fma_(r2, fma_(r2, T(2.718311493989822e-06f), T(-1.984090162742e-04f)), T(8.333329385889463e-03f)), T(-1.666666597127914e-01f));
+    T sr = fma_(r * r2, sp, r);
+    T cp = fma_(r2, fma_(r2, fma_(r2, T(2.443315711809948e-05f), T(-1.388731625493765e-03f)), T(4.166664568298827e-02f)), T(-0.5f));
+    T cr = fma_(r2, cp, T(1.0f));
+    if constexpr (sizeof(T) == sizeof(float)) {
+        sincos_quadrant(k, sr, cr, s, c);
+    } else {
+        sincos_quadrant(k.x, sr.x, cr.x, s.x, c.x);
+        sincos_quadrant(k.y, sr.y, cr.y, s.y, c.y);
+    }
 }
 
 // Divergence guard.  The engine being replaced checks positions / velocities / accelerations every step and resets
@@ -187,42 +245,47 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
 // system matrix as h * (c_t * point-mass(P) + (c_n - c_t) a a^T), a = [P x n; n].
 // Split in two so that the sample points of one body can be shared out over several lanes.
 // ------------------------------------------------------------------------------------------
-DEV void contact_point(V3 r, V3 nl, float zb, float &wsum, V3 &s) {
-    float pen = fmaxf(zb - dot(nl, r), 0.f);
+template <class T> DEV void contact_point(V3T<T> r, V3T<T> nl, T zb, T &wsum, V3T<T> &s) {
+    T pen = max_(zb - dot(nl, r), T(0.f));
     wsum += pen;
     s = fma3(pen, r, s);
 }
-DEV void contact_finish(float wsum, V3 s, const Fr &E, V3 p, V3 n, SV v, float kc, float cmax, float inv_ramp, float mu, float h,
-                        SV &f_ext, Sym6 &A) {
-    bool active = wsum > 0.f;
-    float W = kc * wsum;
-    float cc = cmax * fminf(wsum * inv_ramp, 1.f);
-    float inv = rcp(active ? wsum : 1.f);
-    V3 P = p + rot(E, inv * s);         // centre of pressure, FRAME axes about the FRAME origin
-    V3 vP = v.l + cross(v.a, P);
-    float vn = dot(n, vP);
-    V3 vt = vP - vn * n;
-    float Fn = W - cc * vn;
-    float cn = cc;
-    if (Fn < 0.f) { Fn = 0.f; cn = W * rcp(vn); }
-    float speed = __builtin_amdgcn_sqrtf(dot(vt, vt));
-    float ct = cc;
-    if (cc * speed > mu * Fn) ct = mu * Fn * rcp(speed);
-    if (!active) { Fn = 0.f; cn = 0.f; ct = 0.f; }
-    V3 F = Fn * n - ct * vt;
+template <class T>
+DEV void contact_finish(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp, float mu, float h,
+                        SVT<T> &f_ext, Sym6T<T> &A) {
+    const T zero = T(0.f);
+    auto active = wsum > zero;
+    T W = kc * wsum;
+    T cc = cmax * min_(wsum * inv_ramp, T(1.f));
+    T inv = rcp(sel(active, wsum, T(1.f)));
+    V3T<T> P = p + rot(E, inv * s);         // centre of pressure, FRAME axes about the FRAME origin
+    V3T<T> vP = v.l + cross(v.a, P);
+    T vn = dot(n, vP);
+    V3T<T> vt = vP - vn * n;
+    T Fn0 = W - cc * vn;
+    auto lifted = Fn0 < zero;                // no adhesion: the secant damping coefficient replaces c (vn > 0 here)
+    T Fn = sel(lifted, zero, Fn0);
+    T cn = sel(lifted, W * rcp(vn), cc);
+    T speed = sqrt_(dot(vt, vt));
+    auto sliding = cc * speed > mu * Fn;     // Coulomb limit (speed > 0 here)
+    T ct = sel(sliding, mu * Fn * rcp(speed), cc);
+    Fn = sel(active, Fn, zero);
+    cn = sel(active, cn, zero);
+    ct = sel(active, ct, zero);
+    V3T<T> F = Fn * n - ct * vt;
     f_ext.a = cross(P, F);
     f_ext.l = F;
     add_contact_damping(A, h * ct, h * (cn - ct), P, n);
 }
-template <int NCP>
-DEV void body_contact(const float (*cp)[3], const Fr &E, V3 p, float z_origin, V3 n, SV v, float kc, float cmax, float inv_ramp,
-                      float margin, float mu, float h, SV &f_ext, Sym6 &A) {
-    V3 nl = rotT(E, n);                 // world up in the body's own axes
-    float wsum = 0.f;
-    V3 s = v3(0.f, 0.f, 0.f);
-    float zb = margin - z_origin;
+template <class T, int NCP>
+DEV void body_contact(const float (*cp)[3], const FrT<T> &E, V3T<T> p, T z_origin, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp,
+                      float margin, float mu, float h, SVT<T> &f_ext, Sym6T<T> &A) {
+    V3T<T> nl = rotT(E, n);                 // world up in the body's own axes
+    T wsum = T(0.f);
+    V3T<T> s = v3<T>(T(0.f), T(0.f), T(0.f));
+    T zb = T(margin) - z_origin;
 #pragma unroll
-    for (int i = 0; i < NCP; ++i) contact_point(ld3(cp[i]), nl, zb, wsum, s);
+    for (int i = 0; i < NCP; ++i) contact_point(ld3t<T>(cp[i]), nl, zb, wsum, s);
     contact_finish(wsum, s, E, p, n, v, kc, cmax, inv_ramp, mu, h, f_ext, A);
 }
 
@@ -278,68 +341,71 @@ DEV void frame_body(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic
 // Out: leg composite inertia Ic and force fc (to be added to the base rows), the base coupling
 // columns F[j], the leg block H = [[Hd0,H01,H02],[.,Hd1,H12],[.,.,Hd2]] and the right-hand side b.
 // ------------------------------------------------------------------------------------------
-template <bool BAKED, bool QUAD, bool CULL_FEMUR = false>
-DEV void leg_pass(const KModel &C, int k, Fr Ep, const float q[3], const float qd[3], const float act[3], const BaseCtx &bc, float zbase,
-                  float h, Sym6 &Ic, SV &fc, SV F[3], float Hd[3], float &H01, float &H02, float &H12, float bj[3]) {
-    V3 pp = v3(0.f, 0.f, 0.f);
-    SV vp = bc.V0, ap = bc.A0;
-    SV S[3], f[3];
-    Sym6 Ag[3];
+template <class T, bool BAKED, bool QUAD, bool CULL_FEMUR = false>
+DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3], const T act[3], const BaseCtx &bc, float zbase_f,
+                  float h, Sym6T<T> &Ic, SVT<T> &fc, SVT<T> F[3], T Hd[3], T &H01, T &H02, T &H12, T bj[3]) {
+    const T zero = T(0.f);
+    V3T<T> pp = v3<T>(zero, zero, zero);
+    const V3T<T> nb = splat3<T>(bc.n);
+    const T zbase = T(zbase_f);
+    SVT<T> vp = splat6<T>(bc.V0), ap = splat6<T>(bc.A0);
+    SVT<T> S[3], f[3];
+    Sym6T<T> Ag[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const KLink &L = link_of<BAKED>(C, k, i);
         const KLink &Lm = QUAD ? C.link[i] : ((i == 0) ? C.link[3 * k] : L);   // the fema's mounting transform differs per leg
-        float th = q[i] - L.ref;      // rotation applied = qpos - ref
-        float sn, cs;
+        T th = q[i] - T(L.ref);      // rotation applied = qpos - ref
+        T sn, cs;
         sincos_f(th, sn, cs);
-        V3 p = pp + rot(Ep, ld3(Lm.pos));
-        V3 tx = fma3(Lm.Q[0], Ep.ex, fma3(Lm.Q[3], Ep.ey, Lm.Q[6] * Ep.ez));
-        V3 ty = fma3(Lm.Q[1], Ep.ex, fma3(Lm.Q[4], Ep.ey, Lm.Q[7] * Ep.ez));
-        V3 tz = fma3(Lm.Q[2], Ep.ex, fma3(Lm.Q[5], Ep.ey, Lm.Q[8] * Ep.ez));
-        Fr E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
+        V3T<T> p = pp + rot(Ep, ld3t<T>(Lm.pos));
+        V3T<T> tx = fma3(T(Lm.Q[0]), Ep.ex, fma3(T(Lm.Q[3]), Ep.ey, T(Lm.Q[6]) * Ep.ez));
+        V3T<T> ty = fma3(T(Lm.Q[1]), Ep.ex, fma3(T(Lm.Q[4]), Ep.ey, T(Lm.Q[7]) * Ep.ez));
+        V3T<T> tz = fma3(T(Lm.Q[2]), Ep.ex, fma3(T(Lm.Q[5]), Ep.ey, T(Lm.Q[8]) * Ep.ez));
+        FrT<T> E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
         S[i].a = E.ez;
         S[i].l = cross(p, E.ez);
-        SV v = {fma3(qd[i], S[i].a, vp.a), fma3(qd[i], S[i].l, vp.l)};
+        SVT<T> v = {fma3(qd[i], S[i].a, vp.a), fma3(qd[i], S[i].l, vp.l)};
         // a = a_parent + (v x S) qd
-        SV a;
+        SVT<T> a;
         a.a = fma3(qd[i], cross(v.a, S[i].a), ap.a);
         a.l = fma3(qd[i], cross(v.a, S[i].l) + cross(v.l, S[i].a), ap.l);
         // rigid inertia of the link about the FRAME origin, FRAME axes
-        Rigid Bi;
-        Bi.m = L.mass;
-        V3 c = p + rot(E, ld3(L.ipos));
-        Bi.h = L.mass * c;
+        RigidT<T> Bi;
+        Bi.m = T(L.mass);
+        V3T<T> c = p + rot(E, ld3t<T>(L.ipos));
+        Bi.h = Bi.m * c;
         {
-            V3 ux = fma3(L.inertia[0], E.ex, fma3(L.inertia[3], E.ey, L.inertia[4] * E.ez));
-            V3 uy = fma3(L.inertia[3], E.ex, fma3(L.inertia[1], E.ey, L.inertia[5] * E.ez));
-            V3 uz = fma3(L.inertia[4], E.ex, fma3(L.inertia[5], E.ey, L.inertia[2] * E.ez));
-            float hc = dot(Bi.h, c);
-            Bi.I.xx = fmaf(ux.x, E.ex.x, fmaf(uy.x, E.ey.x, uz.x * E.ez.x)) + hc - Bi.h.x * c.x;
-            Bi.I.yy = fmaf(ux.y, E.ex.y, fmaf(uy.y, E.ey.y, uz.y * E.ez.y)) + hc - Bi.h.y * c.y;
-            Bi.I.zz = fmaf(ux.z, E.ex.z, fmaf(uy.z, E.ey.z, uz.z * E.ez.z)) + hc - Bi.h.z * c.z;
-            Bi.I.xy = fmaf(ux.x, E.ex.y, fmaf(uy.x, E.ey.y, uz.x * E.ez.y)) - Bi.h.x * c.y;
-            Bi.I.xz = fmaf(ux.x, E.ex.z, fmaf(uy.x, E.ey.z, uz.x * E.ez.z)) - Bi.h.x * c.z;
-            Bi.I.yz = fmaf(ux.y, E.ex.z, fmaf(uy.y, E.ey.z, uz.y * E.ez.z)) - Bi.h.y * c.z;
+            V3T<T> ux = fma3(T(L.inertia[0]), E.ex, fma3(T(L.inertia[3]), E.ey, T(L.inertia[4]) * E.ez));
+            V3T<T> uy = fma3(T(L.inertia[3]), E.ex, fma3(T(L.inertia[1]), E.ey, T(L.inertia[5]) * E.ez));
+            V3T<T> uz = fma3(T(L.inertia[4]), E.ex, fma3(T(L.inertia[5]), E.ey, T(L.inertia[2]) * E.ez));
+            T hc = dot(Bi.h, c);
+            Bi.I.xx = fma_(ux.x, E.ex.x, fma_(uy.x, E.ey.x, uz.x * E.ez.x)) + hc - Bi.h.x * c.x;
+            Bi.I.yy = fma_(ux.y, E.ex.y, fma_(uy.y, E.ey.y, uz.y * E.ez.y)) + hc - Bi.h.y * c.y;
+            Bi.I.zz = fma_(ux.z, E.ex.z, fma_(uy.z, E.ey.z, uz.z * E.ez.z)) + hc - Bi.h.z * c.z;
+            Bi.I.xy = fma_(ux.x, E.ex.y, fma_(uy.x, E.ey.y, uz.x * E.ez.y)) - Bi.h.x * c.y;
+            Bi.I.xz = fma_(ux.x, E.ex.z, fma_(uy.x, E.ey.z, uz.x * E.ez.z)) - Bi.h.x * c.z;
+            Bi.I.yz = fma_(ux.y, E.ex.z, fma_(uy.y, E.ey.z, uz.y * E.ez.z)) - Bi.h.y * c.z;
         }
-        SV Iv = mul(Bi, v), Ia = mul(Bi, a);
+        SVT<T> Iv = mul(Bi, v), Ia = mul(Bi, a);
         f[i].a = Ia.a + cross(v.a, Iv.a) + cross(v.l, Iv.l);
         f[i].l = Ia.l + cross(v.a, Iv.l);
         Ag[i] = sym6_of(Bi);
-        float zo = zbase + dot(bc.n, p);
+        T zo = zbase + dot(nb, p);
         bool may = true;
         if (CULL_FEMUR && i == 0) {
             // femur: wave-uniform skip of its contact when no env of the wave can reach the floor with it (bounding sphere
             // of its sample points).  Pays only once several waves share a SIMD (+4.7 % at 262 144 envs, -1.6 % at 4096).
             float b2 = 0.f;
 #pragma unroll
-            for (int q = 0; q < QGK_CP_LINK; ++q) b2 = fmaxf(b2, L.cp[q][0] * L.cp[q][0] + L.cp[q][1] * L.cp[q][1] + L.cp[q][2] * L.cp[q][2]);
-            float reach = zo - C.contact_margin;
-            may = __any(!(reach > 0.f) || reach * reach < b2 * 1.0002f) != 0;
+            for (int qq = 0; qq < QGK_CP_LINK; ++qq) b2 = fmaxf(b2, L.cp[qq][0] * L.cp[qq][0] + L.cp[qq][1] * L.cp[qq][1] + L.cp[qq][2] * L.cp[qq][2]);
+            T reach = zo - T(C.contact_margin);
+            may = __any(m_any(m_or(m_not(reach > zero), reach * reach < T(b2 * 1.0002f)))) != 0;
         }
         if (may) {
-            SV fe;
-            body_contact<QGK_CP_LINK>(L.cp, E, p, zo, bc.n, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
-                                      C.contact_margin, C.contact_mu, h, fe, Ag[i]);
+            SVT<T> fe;
+            body_contact<T, QGK_CP_LINK>(L.cp, E, p, zo, nb, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
+                                         C.contact_margin, C.contact_mu, h, fe, Ag[i]);
             f[i].a = f[i].a - fe.a;
             f[i].l = f[i].l - fe.l;
         }
@@ -349,102 +415,97 @@ DEV void leg_pass(const KModel &C, int k, Fr Ep, const float q[3], const float q
     Ic = Ag[2];
     fc = f[2];
     F[2] = mul(Ic, S[2]);
-    float H22 = dot(S[2], F[2]), t2 = dot(S[2], fc);
+    T H22 = dot(S[2], F[2]), t2 = dot(S[2], fc);
     H12 = dot(S[1], F[2]);
     H02 = dot(S[0], F[2]);
     add(Ic, Ag[1]);
     fc = fc + f[1];
     F[1] = mul(Ic, S[1]);
-    float H11 = dot(S[1], F[1]), t1 = dot(S[1], fc);
+    T H11 = dot(S[1], F[1]), t1 = dot(S[1], fc);
     H01 = dot(S[0], F[1]);
     add(Ic, Ag[0]);
     fc = fc + f[0];
     F[0] = mul(Ic, S[0]);
-    float H00 = dot(S[0], F[0]), t0 = dot(S[0], fc);
+    T H00 = dot(S[0], F[0]), t0 = dot(S[0], fc);
     Hd[0] = H00; Hd[1] = H11; Hd[2] = H22;
-    float tb[3] = {t0, t1, t2};
+    T tb[3] = {t0, t1, t2};
 
-    // joint-space terms: damping, armature, servo, soft limits
+    // joint-space terms: damping, armature, servo, soft limits (masks + select: the same source serves float and f2)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const KLink &L = link_of<BAKED>(C, k, i);
         // position servo (quadruped.xml:10-37): force from the PRE-update activation
-        float force = L.kp * (act[i] - L.gear * q[i]) - L.kv * L.gear * qd[i];
-        bool clamped = (force <= L.force_lo) || (force >= L.force_hi);
-        force = fminf(fmaxf(force, L.force_lo), L.force_hi);
-        float dimp = L.damping + (clamped ? 0.f : L.kv * L.gear * L.gear);
-        float tau = L.gear * force - L.damping * qd[i];
-        // soft joint limits
-        float below = L.lo - q[i], above = q[i] - L.hi;
-        float pen = fmaxf(fmaxf(below, above), 0.f);
-        float bl = C.limit_b * fminf(pen * C.limit_inv_ramp, 1.f);   // damper ramps in: continuous torque
-        if (below > 0.f) {
-            float spring = C.limit_k * below;
-            float t = spring - bl * qd[i];
-            float be = bl;
-            if (t < 0.f) { t = 0.f; be = spring * rcp(qd[i]); }
-            tau += t;
-            dimp += be;
-        } else if (above > 0.f) {
-            float spring = C.limit_k * above;
-            float t = spring + bl * qd[i];
-            float be = bl;
-            if (t < 0.f) { t = 0.f; be = -spring * rcp(qd[i]); }
-            tau -= t;
-            dimp += be;
-        }
-        Hd[i] += L.armature + h * dimp;
+        T force = L.kp * (act[i] - L.gear * q[i]) - (L.kv * L.gear) * qd[i];
+        auto clamped = m_or(force <= T(L.force_lo), force >= T(L.force_hi));
+        force = min_(max_(force, T(L.force_lo)), T(L.force_hi));
+        T dimp = T(L.damping) + sel(clamped, zero, T(L.kv * L.gear * L.gear));
+        T tau = L.gear * force - L.damping * qd[i];
+        // soft joint limits: one-sided spring + damper that ramps in with the penetration (continuous torque)
+        T below = T(L.lo) - q[i], above = q[i] - T(L.hi);
+        T pen = max_(max_(below, above), zero);
+        T bl = C.limit_b * min_(pen * C.limit_inv_ramp, T(1.f));
+        auto is_below = below > zero;
+        auto is_above = m_and(m_not(is_below), above > zero);
+        T spring_b = C.limit_k * below, spring_a = C.limit_k * above;
+        T tq_b = spring_b - bl * qd[i], tq_a = spring_a + bl * qd[i];
+        auto free_b = tq_b < zero, free_a = tq_a < zero;      // leaving the limit fast: no pull-back, secant damping
+        T lim_b = sel(free_b, zero, tq_b), be_b = sel(free_b, spring_b * rcp(qd[i]), bl);
+        T lim_a = sel(free_a, zero, tq_a), be_a = sel(free_a, -spring_a * rcp(qd[i]), bl);
+        tau = tau + sel(is_below, lim_b, zero) - sel(is_above, lim_a, zero);
+        dimp = dimp + sel(is_below, be_b, sel(is_above, be_a, zero));
+        Hd[i] = Hd[i] + T(L.armature) + h * dimp;
         bj[i] = tau - tb[i];
     }
 }
 
 // Block elimination of one leg: LDL^T of the 3x3 joint block, Y = F H^-1 (6x3, stored as three
 // 6-vectors), u = H^-1 b; returns the Schur terms  YFt = Y F^T (symmetric 6x6)  and  Fu = F u.
-DEV void leg_eliminate(const SV F[3], const float Hd[3], float H01, float H02, float H12, const float bj[3], float Y0[6], float Y1[6],
-                       float Y2[6], float u[3], Sym6 &YFt, SV &Fu) {
-    float d0 = Hd[0], id0 = rcp(d0);
-    float l10 = H01 * id0, l20 = H02 * id0;
-    float d1 = fmaf(-l10, H01, Hd[1]), id1 = rcp(d1);
-    float t21 = fmaf(-l20, H01, H12);
-    float l21 = t21 * id1;
-    float d2 = fmaf(-l21, t21, fmaf(-l20, H02, Hd[2])), id2 = rcp(d2);
-    float Fr0[6] = {F[0].a.x, F[0].a.y, F[0].a.z, F[0].l.x, F[0].l.y, F[0].l.z};
-    float Fr1[6] = {F[1].a.x, F[1].a.y, F[1].a.z, F[1].l.x, F[1].l.y, F[1].l.z};
-    float Fr2[6] = {F[2].a.x, F[2].a.y, F[2].a.z, F[2].l.x, F[2].l.y, F[2].l.z};
+template <class T>
+DEV void leg_eliminate(const SVT<T> F[3], const T Hd[3], T H01, T H02, T H12, const T bj[3], T Y0[6], T Y1[6],
+                       T Y2[6], T u[3], Sym6T<T> &YFt, SVT<T> &Fu) {
+    T d0 = Hd[0], id0 = rcp(d0);
+    T l10 = H01 * id0, l20 = H02 * id0;
+    T d1 = fma_(-l10, H01, Hd[1]), id1 = rcp(d1);
+    T t21 = fma_(-l20, H01, H12);
+    T l21 = t21 * id1;
+    T d2 = fma_(-l21, t21, fma_(-l20, H02, Hd[2])), id2 = rcp(d2);
+    T Fr0[6] = {F[0].a.x, F[0].a.y, F[0].a.z, F[0].l.x, F[0].l.y, F[0].l.z};
+    T Fr1[6] = {F[1].a.x, F[1].a.y, F[1].a.z, F[1].l.x, F[1].l.y, F[1].l.z};
+    T Fr2[6] = {F[2].a.x, F[2].a.y, F[2].a.z, F[2].l.x, F[2].l.y, F[2].l.z};
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        float z0 = Fr0[r];
-        float z1 = fmaf(-l10, z0, Fr1[r]);
-        float z2 = fmaf(-l21, z1, fmaf(-l20, z0, Fr2[r]));
-        float y2 = z2 * id2;
-        float y1 = fmaf(-l21, y2, z1 * id1);
-        float y0 = fmaf(-l20, y2, fmaf(-l10, y1, z0 * id0));
+        T z0 = Fr0[r];
+        T z1 = fma_(-l10, z0, Fr1[r]);
+        T z2 = fma_(-l21, z1, fma_(-l20, z0, Fr2[r]));
+        T y2 = z2 * id2;
+        T y1 = fma_(-l21, y2, z1 * id1);
+        T y0 = fma_(-l20, y2, fma_(-l10, y1, z0 * id0));
         Y0[r] = y0; Y1[r] = y1; Y2[r] = y2;
     }
     {
-        float z0 = bj[0];
-        float z1 = fmaf(-l10, z0, bj[1]);
-        float z2 = fmaf(-l21, z1, fmaf(-l20, z0, bj[2]));
+        T z0 = bj[0];
+        T z1 = fma_(-l10, z0, bj[1]);
+        T z2 = fma_(-l21, z1, fma_(-l20, z0, bj[2]));
         u[2] = z2 * id2;
-        u[1] = fmaf(-l21, u[2], z1 * id1);
-        u[0] = fmaf(-l20, u[2], fmaf(-l10, u[1], z0 * id0));
+        u[1] = fma_(-l21, u[2], z1 * id1);
+        u[0] = fma_(-l20, u[2], fma_(-l10, u[1], z0 * id0));
     }
 #define YF(r, c) (Y0[r] * Fr0[c] + Y1[r] * Fr1[c] + Y2[r] * Fr2[c])
     YFt.AA.xx = YF(0, 0); YFt.AA.yy = YF(1, 1); YFt.AA.zz = YF(2, 2);
     YFt.AA.xy = YF(0, 1); YFt.AA.xz = YF(0, 2); YFt.AA.yz = YF(1, 2);
-    YFt.AL.r0 = v3(YF(0, 3), YF(0, 4), YF(0, 5));
-    YFt.AL.r1 = v3(YF(1, 3), YF(1, 4), YF(1, 5));
-    YFt.AL.r2 = v3(YF(2, 3), YF(2, 4), YF(2, 5));
+    YFt.AL.r0 = v3<T>(YF(0, 3), YF(0, 4), YF(0, 5));
+    YFt.AL.r1 = v3<T>(YF(1, 3), YF(1, 4), YF(1, 5));
+    YFt.AL.r2 = v3<T>(YF(2, 3), YF(2, 4), YF(2, 5));
     YFt.LL.xx = YF(3, 3); YFt.LL.yy = YF(4, 4); YFt.LL.zz = YF(5, 5);
     YFt.LL.xy = YF(3, 4); YFt.LL.xz = YF(3, 5); YFt.LL.yz = YF(4, 5);
 #undef YF
-    Fu.a = v3(Fr0[0] * u[0] + Fr1[0] * u[1] + Fr2[0] * u[2], Fr0[1] * u[0] + Fr1[1] * u[1] + Fr2[1] * u[2],
-              Fr0[2] * u[0] + Fr1[2] * u[1] + Fr2[2] * u[2]);
-    Fu.l = v3(Fr0[3] * u[0] + Fr1[3] * u[1] + Fr2[3] * u[2], Fr0[4] * u[0] + Fr1[4] * u[1] + Fr2[4] * u[2],
-              Fr0[5] * u[0] + Fr1[5] * u[1] + Fr2[5] * u[2]);
+    Fu.a = v3<T>(Fr0[0] * u[0] + Fr1[0] * u[1] + Fr2[0] * u[2], Fr0[1] * u[0] + Fr1[1] * u[1] + Fr2[1] * u[2],
+                 Fr0[2] * u[0] + Fr1[2] * u[1] + Fr2[2] * u[2]);
+    Fu.l = v3<T>(Fr0[3] * u[0] + Fr1[3] * u[1] + Fr2[3] * u[2], Fr0[4] * u[0] + Fr1[4] * u[1] + Fr2[4] * u[2],
+                 Fr0[5] * u[0] + Fr1[5] * u[1] + Fr2[5] * u[2]);
 }
-DEV void sub(Sym3 &a, const Sym3 &b) { a.xx -= b.xx; a.yy -= b.yy; a.zz -= b.zz; a.xy -= b.xy; a.xz -= b.xz; a.yz -= b.yz; }
-DEV void sub(Sym6 &a, const Sym6 &b) {
+template <class T> DEV void sub(Sym3T<T> &a, const Sym3T<T> &b) { a.xx -= b.xx; a.yy -= b.yy; a.zz -= b.zz; a.xy -= b.xy; a.xz -= b.xz; a.yz -= b.yz; }
+template <class T> DEV void sub(Sym6T<T> &a, const Sym6T<T> &b) {
     sub(a.AA, b.AA); sub(a.LL, b.LL);
     a.AL.r0 = a.AL.r0 - b.AL.r0; a.AL.r1 = a.AL.r1 - b.AL.r1; a.AL.r2 = a.AL.r2 - b.AL.r2;
 }
@@ -549,7 +610,7 @@ DEV void substep(const KModel *__restrict__ Mp, float *__restrict__ lds, int lan
     {
         Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
         SV fe;
-        body_contact<QGK_CP_FRAME>(C.cp0, E0, v3(0.f, 0.f, 0.f), B.pw.z, bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp,
+        body_contact<float, QGK_CP_FRAME>(C.cp0, E0, v3(0.f, 0.f, 0.f), B.pw.z, bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp,
                                    C.contact_margin, C.contact_mu, h, fe, Ic0);
         p0.a = p0.a - fe.a;
         p0.l = p0.l - fe.l;
@@ -570,7 +631,7 @@ DEV void substep(const KModel *__restrict__ Mp, float *__restrict__ lds, int lan
         Sym6 Ic, YFt;
         SV fc, F[3], Fu;
         float Hd[3], H01, H02, H12, bj[3], Y0[6], Y1[6], Y2[6], u[3];
-        leg_pass<BAKED, false>(C, k, E0, q, qd, act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+        leg_pass<float, BAKED, false>(C, k, E0, q, qd, act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         add(Ic0, Ic);
         sub(Ic0, YFt);
@@ -835,10 +896,10 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         if constexpr (BAKED) {
             // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
             Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<true, true, LOWREG>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+            leg_pass<float, true, true, LOWREG>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         } else {
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<false, false, LOWREG>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+            leg_pass<float, false, false, LOWREG>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
