@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G env-steps (kernel + per-step collective, double-buffered) into one hipGraph and replay it; "
                          "steps and warmup are rounded up to multiples of G.  Validated with a 1-rank RCCL group only: opt-in")
-    ap.add_argument("--mapping", choices=["auto", "lane", "quad"], default="auto", help="work mapping of the step kernel")
+    ap.add_argument("--mapping", choices=["auto", "lane", "quad", "pair"], default="auto", help="work mapping of the step kernel")
     args = ap.parse_args()
 
     import torch
@@ -170,8 +170,9 @@ def main():
         model.body_mass[3] *= 1.001
     sim = BatchedSim(n, device=local_rank, model=model, task=task, env_index_base=rank * n)
     sim.set_track_ctrl(False)
-    sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD}[args.mapping])
-    mapping_name = {_abi.MAP_LANE: "one env per lane", _abi.MAP_QUAD: "one leg per lane (4 lanes per env)"}[sim.mapping]
+    sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}[args.mapping])
+    mapping_name = {_abi.MAP_LANE: "one env per lane", _abi.MAP_QUAD: "one leg per lane (4 lanes per env)",
+                    _abi.MAP_PAIR: "two legs per lane, packed f32 (2 lanes per env)"}[sim.mapping]
     sim.reset(seed=0, flags=task.reset_flags)
     od = sim.obs_dim
     row = od + 2
@@ -316,11 +317,14 @@ def main():
     qpos = sim.get_state()[0]
     healthy = bool(np.isfinite(qpos).all())
 
+    MAP_KEY = {_abi.MAP_LANE: "lane", _abi.MAP_QUAD: "quad", _abi.MAP_PAIR: "pair"}
+    MAP_KERNEL = {_abi.MAP_LANE: "qg_step_kernel", _abi.MAP_QUAD: "qg_step_kernel_quad", _abi.MAP_PAIR: "qg_step_kernel_pair"}
+    MAP_ENVS_PER_WAVE = {_abi.MAP_LANE: 64, _abi.MAP_QUAD: 16, _abi.MAP_PAIR: 32}
     if rank == 0:
         # HBM traffic per launch: committed rocprofv3 PMC measurement of this same configuration, when there is one
         traffic, valu = None, None
         try:
-            key = f"{'quad' if sim.mapping == _abi.MAP_QUAD else 'lane'}_n{n}_fs{args.frame_skip}_obs{od}"
+            key = f"{MAP_KEY[sim.mapping]}_n{n}_fs{args.frame_skip}_obs{od}"
             with open(os.path.join(ROOT, "profiles", "traffic_index.json")) as fh:
                 ent = json.load(fh).get(key)
             if ent:
@@ -349,7 +353,7 @@ def main():
             "substeps_per_sec": value * args.frame_skip,
             "state_finite": healthy,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "qg_step_kernel_quad" if sim.mapping == _abi.MAP_QUAD else "qg_step_kernel",
+                         "traffic": traffic, "kernel": MAP_KERNEL[sim.mapping],
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_step * n,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "VALU-issue-bound path (no dense contraction): ~0.6 KB of state traffic per env-step against "
@@ -357,7 +361,7 @@ def main():
         }
         if valu:
             # issue-rate view of the same launch: wave-instructions/s against 1024 SIMDs x (2.4 GHz / 2 cycles per wave64 VALU op)
-            waves = -(-n // (16 if sim.mapping == _abi.MAP_QUAD else 64))
+            waves = -(-n // MAP_ENVS_PER_WAVE[sim.mapping])
             rate = valu * waves / (kernel_ms * 1e-3)
             line["roofline"]["valu_issue"] = {"insts_per_wave": valu, "waves": waves, "achieved_ginst_s": rate / 1e9,
                                               "peak_ginst_s": 1024 * 2.4 / 2, "frac": rate / (1024 * 1.2e9)}

@@ -55,9 +55,12 @@ extern "C" {
 #define QG_OBS_IMU 1     /* jointpos 12 + accel 3 + gyro 3 + velocimeter 3 = 21 (BASELINE config 5) */
 
 /* work mappings of the step kernel (qg_set_mapping) */
-#define QG_MAP_AUTO 0    /* = QUAD (measured faster at every batch size) */
+#define QG_MAP_AUTO 0    /* QUAD; the measured optimum per size: PAIR for the compiled-in robot when
+                            16384 < n_envs <= 32768 or n_envs >= 57344, QUAD otherwise */
 #define QG_MAP_LANE 1    /* one environment per wavefront lane (64 envs per wave), any model numbers */
 #define QG_MAP_QUAD 2    /* one leg per lane, four lanes per environment (16 envs per wave), any model numbers */
+#define QG_MAP_PAIR 3    /* two legs per lane as packed FP32 pairs, two lanes per environment (32 envs per wave);
+                            compiled-in robot only: qg_set_mapping refuses it for other model numbers */
 
 /* qg_reset flags */
 #define QG_RESET_RANDOM_YAW 1u   /* walking_quad.py:68-75: qpos[3:7] = [cos a/2, 0, 0, sin a/2], a ~ U(0, 2 pi) */
@@ -178,7 +181,7 @@ int qg_set_track_ctrl(qg_sim *sim, int32_t on);
 int qg_uses_baked_model(const qg_sim *sim);
 
 /* Choose how environments map onto wavefront lanes (QG_MAP_*); results agree to rounding.
- * qg_get_mapping returns the mapping the next step will actually use (LANE or QUAD). */
+ * qg_get_mapping returns the mapping the next step will actually use (LANE, QUAD or PAIR). */
 int qg_set_mapping(qg_sim *sim, int32_t mapping);
 int qg_get_mapping(const qg_sim *sim);
 

@@ -12,7 +12,7 @@ import os
 NBODY, NJNT, NQ, NV, NU, NSENSOR, MAXCP, NREWARD = 13, 12, 19, 18, 12, 33, 12, 3
 OBS_FULL, OBS_IMU = 0, 1
 RESET_RANDOM_YAW = 1
-MAP_AUTO, MAP_LANE, MAP_QUAD = 0, 1, 2
+MAP_AUTO, MAP_LANE, MAP_QUAD, MAP_PAIR = 0, 1, 2, 3
 OBS_DIM = {OBS_FULL: 33, OBS_IMU: 21}
 
 

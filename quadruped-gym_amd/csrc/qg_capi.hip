@@ -213,8 +213,15 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
 // register pressure) measured faster than one env per lane at every batch size from 1 Ki to 256 Ki envs
 // (profiles/r01/sweep.txt), so AUTO picks it.  The compiled-in robot runs the variant with literal constants; any other
 // numbers run the variant that stages the model tables in LDS.
+// Between 16 Ki and 32 Ki envs the quad grid needs a second wave on some SIMDs (31-35 us) while the two-legs-per-lane
+// kernel (packed f32, 32 envs per wave) still fits one wave per SIMD (25.6-28.3 us): AUTO takes it there, for the
+// compiled-in robot.  From 56 Ki envs up (>= 1.75 rounds of one pair wave per SIMD) it is ahead again by 4-11 %
+// (interleaved same-box A/B up to 512 Ki envs); in between (32 Ki < n < 56 Ki) and up to 16 Ki quad is faster
+// (profiles/r01/pair_sweep.txt).
 static int effective_mapping(const qg_sim *s) {
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
+    if (s->mapping == QG_MAP_PAIR) return s->baked ? QG_MAP_PAIR : QG_MAP_QUAD;
+    if (s->baked && s->n > 1024 * QGK_QUAD_ENVS && (s->n <= 1024 * QGK_PAIR_ENVS || s->n >= 1792 * QGK_PAIR_ENVS)) return QG_MAP_PAIR;
     return QG_MAP_QUAD;
 }
 
@@ -233,7 +240,11 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.seed = s->seed;
     P.env_index_base = s->env_index_base;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
-    if (effective_mapping(s) == QG_MAP_QUAD) {
+    const int emap = effective_mapping(s);
+    if (emap == QG_MAP_PAIR) {
+        int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
+        hipLaunchKernelGGL(qg_step_kernel_pair, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
+    } else if (emap == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
         if (s->baked) {
@@ -348,7 +359,9 @@ extern "C" int qg_time_step_kernel(qg_sim *s, const float *d_actions, float *d_p
 /* selects whether data.ctrl is written back each step (needed by QuadrupedEnv's `data.ctrl` view; off for raw throughput) */
 extern "C" int qg_set_mapping(qg_sim *s, int32_t mapping) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
-    if (mapping != QG_MAP_AUTO && mapping != QG_MAP_LANE && mapping != QG_MAP_QUAD) return fail(QG_ERR_ARG, "qg_set_mapping: unknown mapping %d", mapping);
+    if (mapping == QG_MAP_PAIR && !s->baked)
+        return fail(QG_ERR_ARG, "qg_set_mapping: the two-legs-per-lane kernel serves the compiled-in robot only");
+    if (mapping != QG_MAP_AUTO && mapping != QG_MAP_LANE && mapping != QG_MAP_QUAD && mapping != QG_MAP_PAIR) return fail(QG_ERR_ARG, "qg_set_mapping: unknown mapping %d", mapping);
     s->mapping = mapping;
     return QG_OK;
 }

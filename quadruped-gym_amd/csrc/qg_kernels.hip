@@ -208,8 +208,10 @@ template <class T> DEV void sincos_f(T x, T &s, T &c) {
     if constexpr (sizeof(T) == sizeof(float)) {
         sincos_quadrant(k, sr, cr, s, c);
     } else {
-        sincos_quadrant(k.x, sr.x, cr.x, s.x, c.x);
-        sincos_quadrant(k.y, sr.y, cr.y, s.y, c.y);
+        float s0, c0, s1, c1;
+        sincos_quadrant(k.x, sr.x, cr.x, s0, c0);
+        sincos_quadrant(k.y, sr.y, cr.y, s1, c1);
+        s.x = s0; s.y = s1; c.x = c0; c.y = c1;
     }
 }
 
@@ -1103,6 +1105,260 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
             P.st.qvel[(6 + j) * n + env] = rst ? 0.f : L.qd[i];
             P.st.act[j * n + env] = rst ? 0.f : L.act[i];
             if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// env-step kernel, TWO LEGS PER LANE (packed FP32): the two lanes 2e, 2e+1 share env e; lane h owns legs 2h and
+// 2h+1 as the two components of f2 quantities, so every fma / mul / add of the leg physics is ONE v_pk_* instruction for
+// both legs.  32 envs per wave.  Base prelude, FRAME terms, 6x6 solve and base integration are scalar and redundant in the
+// two lanes; leg terms are summed over the two components (a scalar add of the two halves of the register pair) and over the
+// lane pair (one DPP add).  Per env this needs ~1.9x fewer instruction issue slots than one leg per lane, which is what
+// bounds large batches (a SIMD retires one non-packed wave64 FP32 instruction per 4 cycles however many waves it holds);
+// at batch sizes that leave most SIMDs idle the quad mapping's shorter per-wave stream is faster.  Compiled-in robot only.
+// ------------------------------------------------------------------------------------------
+DEV float pair_sum(float x) { return x + dpp_quad<0xB1>(x); }      // quad_perm [1,0,3,2]: the other lane of the pair
+DEV float hsum(f2 v) { return v.x + v.y; }
+DEV V3 hsum(V3T<f2> v) { return v3<float>(hsum(v.x), hsum(v.y), hsum(v.z)); }
+DEV V3 pair_sum(V3 a) { return v3<float>(pair_sum(a.x), pair_sum(a.y), pair_sum(a.z)); }
+DEV Sym3 hpsum(const Sym3T<f2> &a) {
+    Sym3 r = {pair_sum(hsum(a.xx)), pair_sum(hsum(a.yy)), pair_sum(hsum(a.zz)), pair_sum(hsum(a.xy)), pair_sum(hsum(a.xz)), pair_sum(hsum(a.yz))};
+    return r;
+}
+DEV Sym6 hpsum(const Sym6T<f2> &a) {
+    Sym6 r;
+    r.AA = hpsum(a.AA);
+    r.LL = hpsum(a.LL);
+    r.AL.r0 = pair_sum(hsum(a.AL.r0)); r.AL.r1 = pair_sum(hsum(a.AL.r1)); r.AL.r2 = pair_sum(hsum(a.AL.r2));
+    return r;
+}
+DEV SV hpsum(const SVT<f2> &v) { SV r = {pair_sum(hsum(v.a)), pair_sum(hsum(v.l))}; return r; }
+
+struct LegPair { f2 q[3], qd[3], act[3], u[3]; };
+
+DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, bool want_sensors, float *__restrict__ row, int half, float &zaxis_z) {
+    const float h = C.h;
+    const BaseCtx bc0 = base_prelude(C, B);
+    V3 gb_keep;
+    Sym6 Ic;
+    SV fc, Fu;
+    f2 Y0[6], Y1[6], Y2[6], u[3];
+    {
+        const BaseCtx &bc = bc0;
+        gb_keep = bc.gb;
+        if (want_sensors) {          // the step's sensordata describes the state at the start of its last substep
+            zaxis_z = bc.cz.z;
+            float *jr = row + 6 * half;                  // legs 2*half and 2*half + 1
+            jr[0] = L.q[0].x; jr[1] = L.q[1].x; jr[2] = L.q[2].x;
+            jr[3] = L.q[0].y; jr[4] = L.q[1].y; jr[5] = L.q[2].y;
+            if (half == 0) {
+                row[15] = B.wb.x; row[16] = B.wb.y; row[17] = B.wb.z;
+                row[18] = B.pw.x; row[19] = B.pw.y; row[20] = B.pw.z;
+                row[21] = B.vw.x; row[22] = B.vw.y; row[23] = B.vw.z;
+                row[24] = bc.cx.x; row[25] = bc.cx.y; row[26] = bc.cx.z;
+                row[27] = bc.cz.x; row[28] = bc.cz.y; row[29] = bc.cz.z;
+                row[30] = bc.vb.x; row[31] = bc.vb.y; row[32] = bc.vb.z;
+            }
+        }
+        // both legs of this lane, each in the frame turned by its quarter turn: there each of them is leg 0
+        const f2 z2 = f2(0.f), o2 = f2(1.f);
+        FrT<f2> Ek = {v3<f2>(cm, sm, z2), v3<f2>(-sm, cm, z2), v3<f2>(z2, z2, o2)};
+        Sym6T<f2> Ic2, YFt2;
+        SVT<f2> fc2, F2[3], Fu2;
+        f2 Hd[3], H01, H02, H12, bj[3];
+        leg_pass<f2, true, true, false>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic2, fc2, F2, Hd, H01, H02, H12, bj);
+        leg_eliminate<f2>(F2, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt2, Fu2);
+        sub(Ic2, YFt2);                     // the two legs' Schur complements
+        Ic = hpsum(Ic2);                    // sum over the two legs of the lane and over the two lanes of the env
+        fc = hpsum(fc2);
+        Fu = hpsum(Fu2);
+    }
+    float x6[6];
+    {
+        const BaseCtx &bc = bc0;
+        SV p0;
+        Sym6 Ic0;
+        frame_body(C, bc, h, p0, Ic0);
+        {   // FRAME contact: this lane evaluates two quarter turns of the three base sample points
+            f2 wsum2 = f2(0.f);
+            V3T<f2> s2 = v3<f2>(f2(0.f), f2(0.f), f2(0.f));
+            const f2 zb = f2(C.contact_margin - B.pw.z);
+            const V3T<f2> n2 = splat3<f2>(bc.n);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                V3 r0 = ld3(C.cp0[4 * o]);
+                contact_point(v3<f2>(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, f2(r0.z)), n2, zb, wsum2, s2);
+            }
+            float wsum = pair_sum(hsum(wsum2));
+            if (__any(wsum > 0.f)) {        // wave-uniform skip, as in the quad kernel
+                V3 s = pair_sum(hsum(s2));
+                Fr E0 = {v3<float>(1.f, 0.f, 0.f), v3<float>(0.f, 1.f, 0.f), v3<float>(0.f, 0.f, 1.f)};
+                SV fe;
+                contact_finish<float>(wsum, s, E0, v3<float>(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
+                p0.a = p0.a - fe.a;
+                p0.l = p0.l - fe.l;
+            }
+        }
+        add(Ic0, Ic);
+        SV b = {v3<float>(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a, v3<float>(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l};
+        base_solve(Ic0, b, x6);
+    }
+    V3 wdot = v3<float>(x6[0], x6[1], x6[2]);
+    V3 acl = v3<float>(x6[3], x6[4], x6[5]);
+    if (want_sensors && half == 0) {
+        row[12] = acl.x - gb_keep.x; row[13] = acl.y - gb_keep.y; row[14] = acl.z - gb_keep.z;   // accelerometer
+    }
+    // back-substitution and integration of this lane's six hinges
+    const f2 *Y[3] = {Y0, Y1, Y2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f2 acc = u[i];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc = fma_(-Y[i][r], f2(x6[r]), acc);
+        L.qd[i] = fma_(f2(h), acc, L.qd[i]);
+        L.q[i] = fma_(f2(h), L.qd[i], L.q[i]);
+        L.act[i] = fma_(L.u[i] - L.act[i], f2(C.link[i].act_decay), L.act[i]);
+    }
+    {
+        const BaseCtx &bc = bc0;
+        base_integrate(bc, h, wdot, acl, B);
+    }
+}
+
+#define QGK_PAIR_ENVS 32    // envs per wave in the two-legs-per-lane kernel
+
+// One wave per SIMD by construction (381 registers): capping it to 256 for two resident waves spills 592 B per lane and
+// measured slower than this variant at every size (profiles/r01/pair_sweep.txt), so there is only this one.
+__global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P) {
+    __shared__ float tile[QGK_PAIR_ENVS * 35];
+    const KModel &C = QG_BAKED_MODEL;
+    const int lane = threadIdx.x;
+    const int half = lane & 1;                      // legs 2*half, 2*half + 1
+    const int el = lane >> 1;                       // env within the wave
+    const int env0 = blockIdx.x * QGK_PAIR_ENVS;
+    const int n = P.n;
+    const bool live = env0 + el < n;
+    const int env = live ? env0 + el : n - 1;       // tail pairs shadow the last env; their stores are masked
+    // quarter turns of this lane's two legs: (cos, sin)(90 deg * k), k = 2*half and 2*half + 1
+    f2 cm, sm;
+    cm.x = half ? -1.f : 1.f; cm.y = 0.f;
+    sm.x = 0.f; sm.y = half ? -1.f : 1.f;
+
+    BaseState B;
+    B.pw = v3<float>(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
+    B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
+    B.vw = v3<float>(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
+    B.wb = v3<float>(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    int nstep = P.st.nstep[env];
+    LegPair L;
+    float aclip[6];
+    float ssq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = 3 * (2 * half + c) + i;
+            float a = fminf(fmaxf(P.actions[(size_t)env * 12 + j], -1.f), 1.f);    // quadruped.py:160
+            aclip[3 * c + i] = a;
+            ssq = fmaf(a, a, ssq);
+            float uu = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
+            float qq = P.st.qpos[(7 + j) * n + env], qv = P.st.qvel[(6 + j) * n + env], aa = P.st.act[j * n + env];
+            if (c == 0) { L.u[i].x = uu; L.q[i].x = qq; L.qd[i].x = qv; L.act[i].x = aa; }
+            else { L.u[i].y = uu; L.q[i].y = qq; L.qd[i].y = qv; L.act[i].y = aa; }
+        }
+    }
+    ssq = pair_sum(ssq);
+
+    float *srow = tile + el * 35;
+    float zaxis_z = 1.f;
+    const int fs = T->frame_skip;
+    const bool lag = T->sensor_lag != 0;
+#pragma unroll 1
+    for (int s = 0; s < fs; ++s) substep_pair(C, cm, sm, B, L, lag && (s == fs - 1), srow, half, zaxis_z);
+    nstep += fs;
+    if (!lag) {
+        BaseState B2 = B;
+        LegPair L2 = L;
+        substep_pair(C, cm, sm, B2, L2, true, srow, half, zaxis_z);
+    }
+
+    float c_fwd = T->w_forward * B.vw.x;
+    float c_ctl = T->w_ctrl * ssq;
+    float c_alive = T->alive_bonus;
+    float reward = c_fwd + c_ctl + c_alive;
+    bool done = nstep >= T->limit_substeps;
+    if (T->use_fall) done = done || (B.pw.z < T->fall_height);
+    {
+        float probe = hsum(L.q[0]) + hsum(L.q[1]) + hsum(L.q[2]) + hsum(L.qd[0]) + hsum(L.qd[1]) + hsum(L.qd[2]);
+        probe = pair_sum(probe) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+        done = done || state_is_bad(probe);
+    }
+    const int od = T->obs_mode == 1 ? 21 : 33;
+    const int row = P.packed ? od + 2 : od;
+    if (T->use_flip) done = done || (zaxis_z < 0.f);
+    if (half == 0) {
+        if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }
+        if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
+    }
+    __syncthreads();
+    {
+        const int live_envs = min(QGK_PAIR_ENVS, n - env0);
+        const int total = live_envs * row;
+        float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
+        if (row == 35) {
+            for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+        } else {
+            for (int e = lane; e < total; e += QGK_WAVE) {
+                int er = e / row, ec = e - er * row;
+                dst[e] = tile[er * 35 + ec];
+            }
+        }
+    }
+    const bool lead = live && half == 0;
+    if (lead && !P.packed) {
+        P.reward[env] = reward;
+        P.done[env] = done ? 1 : 0;
+    }
+    if (lead && P.comps) {
+        P.comps[(size_t)env * 3 + 0] = c_fwd;
+        P.comps[(size_t)env * 3 + 1] = c_ctl;
+        P.comps[(size_t)env * 3 + 2] = c_alive;
+    }
+
+    const bool rst = done && T->auto_reset;
+    if (rst) {
+        B.pw = v3<float>(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+        B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+        if (T->reset_flags & 1u) {
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float sn, cs;
+            sincos_f(0.5f * a, sn, cs);
+            B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+        }
+        B.vw = v3<float>(0.f, 0.f, 0.f);
+        B.wb = v3<float>(0.f, 0.f, 0.f);
+        nstep = 0;
+    }
+    if (lead) {
+        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
+        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
+        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
+        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
+        P.st.nstep[env] = nstep;
+        if (rst) P.st.episode[env] += 1;
+    }
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int j = 3 * (2 * half + c) + i;
+                P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : (c == 0 ? L.q[i].x : L.q[i].y);
+                P.st.qvel[(6 + j) * n + env] = rst ? 0.f : (c == 0 ? L.qd[i].x : L.qd[i].y);
+                P.st.act[j * n + env] = rst ? 0.f : (c == 0 ? L.act[i].x : L.act[i].y);
+                if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[3 * c + i];
+            }
         }
     }
 }

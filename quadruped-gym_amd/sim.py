@@ -133,7 +133,8 @@ class BatchedSim:
         return float(ms.value)
 
     def set_mapping(self, mapping: int):
-        """``_abi.MAP_AUTO`` / ``MAP_LANE`` (one env per lane) / ``MAP_QUAD`` (one leg per lane)."""
+        """``_abi.MAP_AUTO`` / ``MAP_LANE`` (one env per lane) / ``MAP_QUAD`` (one leg per lane) / ``MAP_PAIR`` (two legs per
+        lane, packed f32; built-in robot only)."""
         check(self._lib.qg_set_mapping(self._h, int(mapping)), "qg_set_mapping")
 
     @property

@@ -48,10 +48,10 @@ def gold():
     return dict(np.load(GOLD))
 
 
-MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD}
+MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 @pytest.mark.parametrize("case", ["A", "B"])
 def test_step_matches_golden_vectors(gold, case, mapping):
     """Both work mappings of the step kernel (one env per lane / one leg per lane) against the fixture."""
@@ -85,7 +85,7 @@ def test_step_matches_golden_vectors(gold, case, mapping):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 def test_step_matches_oracle_on_fresh_states(oracle, mapping):
     """Seeded states the fixture does not hold, through the device-pointer entry points."""
     import torch
@@ -208,7 +208,7 @@ def test_random_yaw_reset_matches_oracle_stream(oracle):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 def test_time_limit_terminates_and_auto_reset(mapping):
     """`time >= max_time` is reported as terminated on the exact substep the f64-accumulated clock
     crosses it (quadruped.py:149-151); with auto_reset the env restarts inside the same launch."""
@@ -234,7 +234,7 @@ def test_time_limit_terminates_and_auto_reset(mapping):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 def test_full_size_invariants(mapping):
     """BASELINE config 2 size (4096 envs): properties that need no oracle."""
     import torch
@@ -270,7 +270,7 @@ def test_full_size_invariants(mapping):
     sim.close(); sim2.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 def test_diverged_envs_are_reported_done_and_reset(mapping):
     """A state with NaN / Inf (here injected through set_state) must not linger: the env is reported done and,
     with auto_reset, restarts -- the counterpart of the engine's own bad-state reset."""
@@ -291,28 +291,47 @@ def test_diverged_envs_are_reported_done_and_reset(mapping):
     sim.close()
 
 
+def test_auto_mapping_policy():
+    """AUTO = the measured optimum per batch size (profiles/r01/pair_sweep.txt); a modified robot never takes PAIR."""
+    from quadruped_gym_amd.sim import BatchedSim
+    for n, want in ((4096, _abi.MAP_QUAD), (16384, _abi.MAP_QUAD), (16385, _abi.MAP_PAIR), (32768, _abi.MAP_PAIR), (32769, _abi.MAP_QUAD),
+                    (57343, _abi.MAP_QUAD), (57344, _abi.MAP_PAIR)):
+        sim = BatchedSim(n)
+        assert sim.baked and sim.mapping == want, (n, sim.mapping)
+        sim.close()
+    m = _abi.default_model()
+    m.contact_friction = 0.7
+    sim = BatchedSim(20000, model=m)
+    assert not sim.baked and sim.mapping == _abi.MAP_QUAD
+    with pytest.raises(RuntimeError, match="compiled-in robot"):
+        sim.set_mapping(_abi.MAP_PAIR)
+    assert sim.mapping == _abi.MAP_QUAD
+    sim.close()
+
+
 def test_mappings_agree_with_each_other():
-    """The two mappings run the same arithmetic per leg; only the order of the four-leg sums differs,
+    """The mappings run the same arithmetic per leg; only the order of the four-leg sums differs,
     so a 50-step rollout from reset stays within rounding-level drift of one another."""
     from quadruped_gym_amd.sim import BatchedSim
     n = 256
-    sims = [BatchedSim(n), BatchedSim(n)]
+    sims = [BatchedSim(n), BatchedSim(n), BatchedSim(n)]
     sims[0].set_mapping(_abi.MAP_LANE)
     sims[1].set_mapping(_abi.MAP_QUAD)
+    sims[2].set_mapping(_abi.MAP_PAIR)
     rng = np.random.default_rng(21)
     for k in range(50):
         a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
-        o0 = sims[0].step(a)
-        o1 = sims[1].step(a)
+        o = [s.step(a) for s in sims]
         if k == 0:
-            assert np.allclose(o0[0], o1[0], atol=1e-4, rtol=1e-4)
-    q0, q1 = sims[0].get_state()[0], sims[1].get_state()[0]
-    assert np.allclose(q0, q1, atol=5e-3)
+            assert np.allclose(o[0][0], o[1][0], atol=1e-4, rtol=1e-4)
+            assert np.allclose(o[0][0], o[2][0], atol=1e-4, rtol=1e-4)
+    q = [s.get_state()[0] for s in sims]
+    assert np.allclose(q[0], q[1], atol=5e-3) and np.allclose(q[0], q[2], atol=5e-3)
     for s in sims:
         s.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 def test_sharding_does_not_change_results(mapping):
     """Two handles of 128 envs with env_index_base 0 / 128 reproduce one handle of 256 bit for bit
     (per-env random streams are keyed by the global env index)."""
