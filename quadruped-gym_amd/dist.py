@@ -89,3 +89,51 @@ class PackedGatherer:
         if self.out is None:
             return None
         return self.flat[b]
+
+
+class ActionScatterer:
+    """The other direction of the per-step exchange: the learner rank holds the actions of the whole batch,
+    ``[world * n, 12]`` f32 in global env order, and every rank receives the ``[n, 12]`` slice of the envs it owns.
+
+    One ``torch.distributed.scatter`` per env-step (RCCL over xGMI on GPUs, gloo on CPU), asynchronous like
+    ``PackedGatherer``: ``submit(all_actions)`` on the source rank (``None`` elsewhere) returns at once, ``wait()`` orders the
+    current stream (RCCL) or the host (gloo) after the transfer and returns this rank's slice.  Double-buffered, so the
+    scatter of step t+1 may be issued while the physics of step t still reads the previous slice.
+    """
+
+    def __init__(self, n_local: int, width: int, device, src: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.src = src
+        self.n, self.width = int(n_local), int(width)
+        self.device = torch.device(device)
+        self.local = [torch.empty((self.n, self.width), device=self.device, dtype=torch.float32) for _ in range(2)]
+        self.work = [None, None]
+        self.k = 0
+        self.pending = []
+
+    def submit(self, all_actions=None):
+        b = self.k & 1
+        chunks = None
+        if self.rank == self.src:
+            if all_actions is None or tuple(all_actions.shape) != (self.world * self.n, self.width):
+                raise ValueError(f"the source rank must pass a [{self.world * self.n}, {self.width}] tensor")
+            if all_actions.dtype != self.local[b].dtype or not all_actions.is_contiguous():
+                raise ValueError("actions must be contiguous float32")
+            chunks = list(all_actions.view(self.world, self.n, self.width).unbind(0))
+        if len(self.pending) == 2:
+            raise RuntimeError("two scatters are outstanding: call wait() before submitting a third")
+        self.work[b] = self.dist.scatter(self.local[b], chunks, src=self.src, group=self.group, async_op=True)
+        self.pending.append(b)
+        self.k += 1
+
+    def wait(self):
+        """This rank's ``[n, width]`` slice of the oldest outstanding scatter."""
+        b = self.pending.pop(0)
+        self.work[b].wait()
+        self.work[b] = None
+        return self.local[b]

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from quadruped_gym_amd.dist import PackedGatherer, shard_range
+from quadruped_gym_amd.dist import ActionScatterer, PackedGatherer, shard_range
 
 
 def test_shard_range_partitions_contiguously():
@@ -65,3 +65,57 @@ def test_gather_world2_gloo():
         assert out.shape == (world * n, row)
         assert np.array_equal(out[:, 0], np.arange(world * n))        # global env order
         assert (out[:, 1:] == k).all()                                # the k-th collect returns the k-th submit
+
+
+def _scatter_worker(rank, world, port, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = ActionScatterer(n, 12, "cpu", src=0)
+    gather = PackedGatherer(n, 14, "cpu", dst=0)
+    ok = True
+    for k in range(steps):
+        full = None
+        if rank == 0:      # the learner's actions for the whole batch: entry = global env index + step / 100 + column / 10000
+            full = (torch.arange(world * n, dtype=torch.float32)[:, None] + k / 100.0 + torch.arange(12)[None, :] / 10000.0).contiguous()
+        sc.submit(full)
+        mine = sc.wait()
+        start, _ = shard_range(world * n, world, rank)
+        want = torch.arange(start, start + n, dtype=torch.float32)[:, None] + k / 100.0 + torch.arange(12)[None, :] / 10000.0
+        ok = ok and bool(torch.equal(mine, want))
+        # closed loop: what each rank "simulated" from its slice comes back in global env order
+        packed = torch.cat([mine, torch.full((n, 2), float(rank))], dim=1)
+        gather.wait_buffer_free()
+        gather.submit(packed)
+        out = gather.collect()
+        if rank == 0:
+            ok = ok and bool(torch.equal(out[:, :12], full))
+    if rank == 0:
+        try:
+            sc.submit(torch.zeros((3, 12)))
+            ok = False
+        except ValueError:
+            pass
+    flags = [None] * world
+    dist.all_gather_object(flags, ok)
+    if rank == 0:
+        q.put(flags)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_action_scatter_world2_gloo():
+    """SURVEY §8e downward leg: [N,12] actions from the learner rank to the rank that owns each env, and the closed
+    loop scatter -> (step) -> gather returns rows in global env order."""
+    world, n, steps = 2, 6, 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    [p.start() for p in procs]
+    flags = q.get(timeout=120)
+    [p.join(timeout=60) for p in procs]
+    assert flags == [True] * world
