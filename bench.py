@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--frame-skip", type=int, default=4)
     ap.add_argument("--obs-mode", type=int, default=0, help="0: 33 sensors, 1: 21-value IMU+joint pack")
     ap.add_argument("--random-yaw", action="store_true", help="BASELINE config 3: random heading at every (re)set")
+    ap.add_argument("--joint-jitter", type=float, default=0.0, metavar="RAD",
+                    help="BASELINE config 3 option: hinges restart at qpos0 + RAD * U(-1,1) at every (re)set")
     ap.add_argument("--sync-gather", action="store_true", help="do not overlap the RCCL gather with the next step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,7 +165,9 @@ def main():
     task.use_fall = 1
     task.fall_height = 0.05
     task.auto_reset = 1
-    task.reset_flags = _abi.RESET_RANDOM_YAW if args.random_yaw else 0
+    task.reset_flags = (_abi.RESET_RANDOM_YAW if args.random_yaw else 0) | (_abi.RESET_JOINT_JITTER if args.joint_jitter > 0 else 0)
+    if args.joint_jitter > 0:
+        task.reset_joint_jitter = args.joint_jitter
     model = None
     if args.generic_model:
         model = _abi.default_model()
@@ -344,6 +348,7 @@ def main():
                                    f"forward+control_cost+alive rewards, fall(z<0.05)+time-limit terminations, auto-reset, "
                                    f"obs={od} f32, U(-1,1) actions resident in HBM"
                                    + (", random yaw at reset" if args.random_yaw else "")
+                                   + (f", hinge jitter {args.joint_jitter} rad at reset" if args.joint_jitter > 0 else "")
                                    + (f", hipGraph of {args.graph} env-steps per replay" if args.graph > 0 else "")
                                    + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
                                    + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 from the library's C loop (qg_comm_rollout, overlapped)" if native is not None else

@@ -64,6 +64,8 @@ extern "C" {
 
 /* qg_reset flags */
 #define QG_RESET_RANDOM_YAW 1u   /* walking_quad.py:68-75: qpos[3:7] = [cos a/2, 0, 0, sin a/2], a ~ U(0, 2 pi) */
+#define QG_RESET_JOINT_JITTER 2u /* hinge j starts at qpos0 + reset_joint_jitter * U(-1, 1), clamped to its range (the reference's open
+                                    "RANDOMIZE ENVIRONMENT - Starting pose, joints" item, TODO.md:8; SURVEY config 3 option) */
 
 /* Robot constants: what mujoco.MjModel.from_xml_path (quadruped.py:59) compiles
  * out of scene.xml.  Topology is fixed (body 0 = FRAME with the free joint, body
@@ -116,6 +118,7 @@ typedef struct qg_task {
     int32_t auto_reset;        /* 1 = envs that finish are reset inside the step (VecEnv semantics) */
     uint32_t reset_flags;      /* QG_RESET_* applied by auto-reset */
     double default_ctrl[QG_NU];/* quadruped.py:124: [0, 0, -0.5] * 4 */
+    double reset_joint_jitter; /* [rad] half-width of the QG_RESET_JOINT_JITTER draw, default 0.1 */
 } qg_task;
 
 typedef struct qg_sim qg_sim;  /* opaque */
@@ -239,6 +242,23 @@ int qg_walk_reset(qg_walk *walk, const uint8_t *mask, uint64_t seed, uint32_t fl
 int qg_walk_step(qg_walk *walk, const float *actions, float *obs, float *reward, uint8_t *done, float *components);
 int qg_walk_step_device(qg_walk *walk, const float *actions, float *obs, float *reward, uint8_t *done, float *components,
                         void *stream);
+/* VelocityHeadingControls.sample(options) (control_inputs.py:74-115) on the device: with a sampler installed every
+ * qg_walk_reset and every in-step auto-reset draws a new command for the envs it resets (random_controls,
+ * walking_quad.py:121-122), from streams 13..15 of the env's (seed, global env index, episode) key -- the reference
+ * draws from the global NumPy RNG, which a batch cannot reproduce.  theta, alpha ~ U(-pi, pi), speed ~ U(min, max)
+ * unless the corresponding QG_CMD_FIXED_* bit selects the fixed value.  The new command takes effect after the
+ * step's reward and (PO) observation have been produced, as in the reference.  NULL removes the sampler. */
+#define QG_CMD_FIXED_HEADING 1u          /* options['fixed_heading_angle'] */
+#define QG_CMD_FIXED_VELOCITY_ANGLE 2u   /* options['fixed_velocity_angle'] */
+#define QG_CMD_FIXED_SPEED 4u            /* options['fixed_speed'] */
+typedef struct qg_command_sampler {
+    uint32_t fixed;                      /* QG_CMD_FIXED_* */
+    double min_speed, max_speed;         /* defaults 0, 1 */
+    double fixed_heading_angle, fixed_velocity_angle, fixed_speed;
+} qg_command_sampler;
+int qg_walk_set_command_sampler(qg_walk *walk, const qg_command_sampler *sampler);
+/* Current commands, host pointers [n][2] each (either may be NULL). */
+int qg_walk_get_commands(qg_walk *walk, float *velocity_xy, float *heading_xy);
 /* Snapshot of the estimator outputs (f_est, a_est: [n][12], host pointers) and the ideal position ([n][2]). */
 int qg_walk_get_estimates(qg_walk *walk, float *f_est, float *a_est, float *ideal_xy);
 

@@ -52,6 +52,8 @@ def lib():
         dp = C.POINTER(C.c_double)
         L.qgo_uniform.restype = C.c_double
         L.qgo_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.qgo_uniform_stream.restype = C.c_double
+        L.qgo_uniform_stream.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
         L.qgo_time_limit_substeps.restype = C.c_int64
         L.qgo_time_limit_substeps.argtypes = [C.c_double, C.c_double]
         L.qgo_reset.argtypes = [C.POINTER(QgModel), C.POINTER(QgTask), C.POINTER(Env), C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]

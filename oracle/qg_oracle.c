@@ -528,6 +528,11 @@ double qgo_uniform(uint64_t seed, uint64_t env_index, uint64_t counter) {
     return (double)(x >> 40) * (1.0 / 16777216.0);
 }
 
+/* independent streams of one (seed, env, episode) key: 0 = reset yaw, 1..12 = hinge jitter, 13..15 = walking command */
+double qgo_uniform_stream(uint64_t seed, uint64_t env_index, uint64_t counter, uint32_t stream) {
+    return qgo_uniform(seed + 0xA0761D6478BD642Full * (uint64_t)stream, env_index, counter);
+}
+
 /* QuadrupedEnv.reset (quadruped.py:115-139): mj_resetData, time = 0, ctrl = default.
  * With QG_RESET_RANDOM_YAW the heading of walking_quad.py:68-75 is applied. */
 int qgo_reset(const qg_model *m, const qg_task *t, qgo_env *e, uint64_t seed, uint64_t env_index, uint64_t counter,
@@ -540,6 +545,15 @@ int qgo_reset(const qg_model *m, const qg_task *t, qgo_env *e, uint64_t seed, ui
     if (flags & QG_RESET_RANDOM_YAW) {
         double a = 6.283185307179586 * qgo_uniform(seed, env_index, counter);
         e->qpos[3] = cos(0.5 * a); e->qpos[4] = 0; e->qpos[5] = 0; e->qpos[6] = sin(0.5 * a);
+    }
+    if (flags & QG_RESET_JOINT_JITTER) {   /* TODO.md:8 "RANDOMIZE ENVIRONMENT - Starting pose, joints": hinge j = qpos0 + jitter * U(-1,1), in range */
+        for (int j = 0; j < QG_NJNT; j++) {
+            double u = qgo_uniform_stream(seed, env_index, counter, 1u + (uint32_t)j);
+            double q = e->qpos[7 + j] + t->reset_joint_jitter * (2.0 * u - 1.0);
+            if (q < m->jnt_range[j][0]) q = m->jnt_range[j][0];
+            if (q > m->jnt_range[j][1]) q = m->jnt_range[j][1];
+            e->qpos[7 + j] = q;
+        }
     }
     return 0;
 }
@@ -620,6 +634,7 @@ int qgo_default_task(qg_task *out) {
     out->w_forward = 1.0; out->w_ctrl = -0.1; out->alive_bonus = 1.0; out->obs_mode = QG_OBS_FULL;
     out->sensor_lag = 1; out->auto_reset = 0; out->reset_flags = 0;
     for (int i = 0; i < NU; i++) out->default_ctrl[i] = (i % 3 == 2) ? -0.5 : 0.0;
+    out->reset_joint_jitter = 0.1;
     return 0;
 }
 int qgo_mass_matrix(const qg_model *m, const double *qpos, double *M) {

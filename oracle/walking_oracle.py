@@ -143,6 +143,26 @@ class Controls:
         self.set_velocity_speed_alpha(i, speed, alpha)
 
 
+def sample_keyed(controls, i, options, seed, env_index, counter):
+    """``Controls.sample`` (control_inputs.py:74-115) with the batch path's counter-based draws in place of the global NumPy
+    RNG: env ``env_index`` in episode ``counter`` takes heading angle, velocity angle and speed from streams 13, 14, 15 of
+    its key (a fixed quantity leaves its stream unused)."""
+    from oracle import oracle as _o
+
+    def u(stream):
+        return _o.lib().qgo_uniform_stream(int(seed), int(env_index), int(counter), stream)
+    options = options or {}
+    lo, hi = options.get("min_speed", 0.0), options.get("max_speed", 1.0)
+    th = options.get("fixed_heading_angle")
+    theta = th if th is not None else -np.pi + 2 * np.pi * u(13)
+    controls.set_orientation(i, theta)
+    al = options.get("fixed_velocity_angle")
+    alpha = al if al is not None else -np.pi + 2 * np.pi * u(14)
+    sp = options.get("fixed_speed")
+    speed = sp if sp is not None else lo + (hi - lo) * u(15)
+    controls.set_velocity_speed_alpha(i, speed, alpha)
+
+
 class WalkingOracle:
     """The task layer around the physics step, for n envs (walking_quad.py:96-148,352-428).
 

@@ -12,6 +12,8 @@ import os
 NBODY, NJNT, NQ, NV, NU, NSENSOR, MAXCP, NREWARD = 13, 12, 19, 18, 12, 33, 12, 3
 OBS_FULL, OBS_IMU = 0, 1
 RESET_RANDOM_YAW = 1
+RESET_JOINT_JITTER = 2
+CMD_FIXED_HEADING, CMD_FIXED_VELOCITY_ANGLE, CMD_FIXED_SPEED = 1, 2, 4
 MAP_AUTO, MAP_LANE, MAP_QUAD, MAP_PAIR = 0, 1, 2, 3
 OBS_DIM = {OBS_FULL: 33, OBS_IMU: 21}
 
@@ -69,7 +71,33 @@ class QgTask(C.Structure):
         ("auto_reset", C.c_int32),
         ("reset_flags", C.c_uint32),
         ("default_ctrl", C.c_double * NU),
+        ("reset_joint_jitter", C.c_double),
     ]
+
+
+class QgCommandSampler(C.Structure):
+    """``qg_command_sampler``: the options of ``VelocityHeadingControls.sample`` (``control_inputs.py:74-115``)."""
+    _fields_ = [
+        ("fixed", C.c_uint32),
+        ("min_speed", C.c_double),
+        ("max_speed", C.c_double),
+        ("fixed_heading_angle", C.c_double),
+        ("fixed_velocity_angle", C.c_double),
+        ("fixed_speed", C.c_double),
+    ]
+
+    @classmethod
+    def from_options(cls, options=None):
+        o = options or {}
+        s = cls()
+        s.min_speed, s.max_speed = float(o.get("min_speed", 0.0)), float(o.get("max_speed", 1.0))
+        for bit, key, field in ((CMD_FIXED_HEADING, "fixed_heading_angle", "fixed_heading_angle"),
+                                (CMD_FIXED_VELOCITY_ANGLE, "fixed_velocity_angle", "fixed_velocity_angle"),
+                                (CMD_FIXED_SPEED, "fixed_speed", "fixed_speed")):
+            if o.get(key) is not None:
+                s.fixed |= bit
+                setattr(s, field, float(o[key]))
+        return s
 
 
 class QgWalkParams(C.Structure):
@@ -159,6 +187,8 @@ def load_library():
     lib.qg_walk_step.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qg_walk_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.qg_walk_get_estimates.argtypes = [vp, vp, vp, vp]
+    lib.qg_walk_set_command_sampler.argtypes = [vp, vp]
+    lib.qg_walk_get_commands.argtypes = [vp, vp, vp]
     lib.qg_po_create.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     lib.qg_po_destroy.argtypes = [vp]
     lib.qg_po_obs_dim.argtypes = [vp]
@@ -180,7 +210,7 @@ EXPORTS = (
     "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
     "qg_comm_unique_id", "qg_comm_create", "qg_comm_destroy", "qg_comm_rollout", "qg_comm_synchronize",
     "qg_walk_default_params", "qg_walk_create", "qg_walk_destroy", "qg_walk_set_commands", "qg_walk_reset", "qg_walk_step",
-    "qg_walk_step_device", "qg_walk_get_estimates",
+    "qg_walk_step_device", "qg_walk_get_estimates", "qg_walk_set_command_sampler", "qg_walk_get_commands",
     "qg_po_create", "qg_po_destroy", "qg_po_obs_dim", "qg_po_reset", "qg_po_step", "qg_po_step_device",
 )
 

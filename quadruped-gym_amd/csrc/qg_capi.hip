@@ -86,6 +86,7 @@ extern "C" int qg_default_task(qg_task *out) {
     out->auto_reset = 0;
     out->reset_flags = 0;
     for (int i = 0; i < QG_NU; i++) out->default_ctrl[i] = (i % 3 == 2) ? -0.5 : 0.0;   // quadruped.py:124
+    out->reset_joint_jitter = 0.1;
     return QG_OK;
 }
 
@@ -581,7 +582,9 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     }
     s->track_ctrl = 1;
     *out = w;
-    int rc = qg_walk_reset(w, nullptr, 0, 0);
+    s->creating = 1;                     // the constructor's own reset does not count as an episode
+    int rc = qg_walk_reset(w, nullptr, s->seed, 0);
+    s->creating = 0;
     if (rc != QG_OK) { qg_walk_destroy(w); *out = nullptr; }
     return rc;
 }
@@ -609,6 +612,55 @@ extern "C" int qg_walk_set_commands(qg_walk *w, const float *velocity_xy, const 
     return QG_OK;
 }
 
+// new commands for the envs `select` marks (device pointer, NULL = all); no-op without a sampler
+static int walk_sample_commands(qg_walk *w, const uint8_t *select, hipStream_t st) {
+    if (!w->kp.cmd_sample) return QG_OK;
+    qg_sim *s = w->sim;
+    int threads = 256, blocks = (s->n + threads - 1) / threads;
+    hipLaunchKernelGGL(qg_walk_command_kernel, dim3(blocks), dim3(threads), 0, st, w->kp, w->st, s->n, select, s->seed, s->env_index_base,
+                       (const int32_t *)s->st.episode);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_walk_command_kernel launch: %s", hipGetErrorString(e));
+    return QG_OK;
+}
+
+extern "C" int qg_walk_set_command_sampler(qg_walk *w, const qg_command_sampler *c) {
+    if (!w) return fail(QG_ERR_ARG, "null handle");
+    KWalkParams &k = w->kp;
+    if (!c) { k.cmd_sample = 0; return QG_OK; }
+    if (c->fixed & ~7u) return fail(QG_ERR_ARG, "qg_walk_set_command_sampler: unknown bits in `fixed`");
+    if (!(c->fixed & QG_CMD_FIXED_SPEED) && !(std::fabs(c->min_speed) < 1e30 && std::fabs(c->max_speed) < 1e30))
+        return fail(QG_ERR_ARG, "qg_walk_set_command_sampler: min_speed / max_speed must be finite");
+    k.cmd_fixed = c->fixed;
+    k.cmd_min_speed = (float)c->min_speed;
+    k.cmd_max_speed = (float)c->max_speed;
+    k.cmd_theta = (float)c->fixed_heading_angle;
+    k.cmd_alpha = (float)c->fixed_velocity_angle;
+    k.cmd_speed = (float)c->fixed_speed;
+    k.cmd_sample = 1;
+    return QG_OK;
+}
+
+extern "C" int qg_walk_get_commands(qg_walk *w, float *velocity_xy, float *heading_xy) {
+    if (!w) return fail(QG_ERR_ARG, "null handle");
+    qg_sim *s = w->sim;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    size_t n = (size_t)s->n;
+    float *host = new (std::nothrow) float[2 * n];
+    if (!host) return fail(QG_ERR_ALLOC, "out of host memory");
+    float *dsts[2] = {velocity_xy, heading_xy};
+    const float *srcs[2] = {w->st.vel, w->st.head};
+    for (int a = 0; a < 2; a++) {
+        if (!dsts[a]) continue;
+        hipError_t e = hipMemcpy(host, srcs[a], 2 * n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete[] host; return fail(QG_ERR_DEVICE, "qg_walk_get_commands: %s", hipGetErrorString(e)); }
+        for (size_t i = 0; i < n; i++) { dsts[a][2 * i] = host[i]; dsts[a][2 * i + 1] = host[n + i]; }
+    }
+    delete[] host;
+    return QG_OK;
+}
+
 extern "C" int qg_walk_reset(qg_walk *w, const uint8_t *mask, uint64_t seed, uint32_t flags) {
     if (!w) return fail(QG_ERR_ARG, "null handle");
     qg_sim *s = w->sim;
@@ -617,12 +669,17 @@ extern "C" int qg_walk_reset(qg_walk *w, const uint8_t *mask, uint64_t seed, uin
     int threads = 256, blocks = (s->n + threads - 1) / threads;
     hipLaunchKernelGGL(qg_walk_reset_kernel, dim3(blocks), dim3(threads), 0, s->stream, w->kp, w->st, s->n, mask ? s->d_mask : nullptr);
     HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    if (!s->creating) {                                // walking_quad.py:121-122 (not for the constructor's own reset)
+        rc = walk_sample_commands(w, mask ? s->d_mask : nullptr, s->stream);
+        if (rc != QG_OK) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
     return QG_OK;
 }
 
-extern "C" int qg_walk_step_device(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream) {
-    if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step_device: null argument");
+// pre + physics + post.  The commands of auto-reset envs are redrawn by the caller AFTER everything that still reads the old
+// ones (the partially observable pack) has been launched.
+static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream) {
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     hipStream_t st = (hipStream_t)stream;
@@ -637,6 +694,13 @@ extern "C" int qg_walk_step_device(qg_walk *w, const float *actions, float *obs,
                        (const uint8_t *)done, reward, components);
     HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
     return QG_OK;
+}
+
+extern "C" int qg_walk_step_device(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream) {
+    if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step_device: null argument");
+    int rc = walk_step_core(w, actions, obs, reward, done, components, stream);
+    if (rc != QG_OK) return rc;
+    return w->kp.auto_reset ? walk_sample_commands(w, done, (hipStream_t)stream) : QG_OK;
 }
 
 extern "C" int qg_walk_step(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components) {
@@ -771,14 +835,14 @@ extern "C" int qg_po_step_device(qg_po *p, const float *actions, float *obs, flo
     if (!p || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_po_step_device: null argument");
     qg_walk *w = p->walk;
     qg_sim *s = w->sim;
-    int rc = qg_walk_step_device(w, actions, p->d_obs33, reward, done, components, stream);
+    int rc = walk_step_core(w, actions, p->d_obs33, reward, done, components, stream);
     if (rc != QG_OK) return rc;
     int threads = 128, blocks = (s->n + threads - 1) / threads;
     hipLaunchKernelGGL(qg_po_frame_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, p->kp, p->st, s->n, (const float *)p->d_obs33,
                        (const float *)w->st.eff_actions, (const float *)s->st.qpos, (const float *)w->st.vel, (const float *)w->st.head,
                        (const uint8_t *)done, obs, terminal_obs);
     HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
-    return QG_OK;
+    return w->kp.auto_reset ? walk_sample_commands(w, done, (hipStream_t)stream) : QG_OK;   // after the frames that show the old command
 }
 
 extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *reward, uint8_t *done, float *components, float *terminal_obs) {

@@ -49,6 +49,7 @@ struct KTask {
     int32_t auto_reset;
     uint32_t reset_flags;
     float default_ctrl[12];
+    float reset_joint_jitter;
 };
 
 // Struct-of-arrays state in HBM: field-major, env-minor, so that lane i of a wave

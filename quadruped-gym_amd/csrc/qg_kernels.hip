@@ -236,6 +236,20 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
     x = mix64(mix64(x));
     return (float)(uint32_t)(x >> 40) * (1.0f / 16777216.0f);
 }
+// independent streams of the same (seed, env, episode) key: 0 = reset yaw, 1..12 = hinge jitter, 13..15 = walking command
+#define QG_STREAM_HINGE 1u
+#define QG_STREAM_COMMAND 13u
+DEV float uniform24s(uint64_t seed, uint64_t env_index, uint64_t counter, uint32_t stream) {
+    return uniform24(seed + 0xA0761D6478BD642Full * (uint64_t)stream, env_index, counter);
+}
+// start value of hinge j at a reset: qpos0, or with QG_RESET_JOINT_JITTER qpos0 + jitter * U(-1, 1) kept inside the joint range
+DEV float reset_hinge(float q0, float lo, float hi, float jitter, uint32_t flags, uint64_t seed, uint64_t env_index, int episode, int j) {
+    if (flags & 2u) {
+        float u = uniform24s(seed, env_index, (uint64_t)episode, QG_STREAM_HINGE + (uint32_t)j);
+        q0 = fminf(fmaxf(fmaf(jitter, 2.f * u - 1.f, q0), lo), hi);
+    }
+    return q0;
+}
 
 // ------------------------------------------------------------------------------------------
 // ground contact of one body: LCP-free penalty model, one aggregated contact per body
@@ -807,8 +821,9 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
     if (rst) {
         B.pw = v3(M->qpos0[0], M->qpos0[1], M->qpos0[2]);
         B.qw = M->qpos0[3]; B.qx = M->qpos0[4]; B.qy = M->qpos0[5]; B.qz = M->qpos0[6];
+        const int ep = P.st.episode[env];
         if (T->reset_flags & 1u) {   // random heading (walking_quad.py:68-75)
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)ep);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
             B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
@@ -816,6 +831,12 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
         B.vw = v3(0.f, 0.f, 0.f);
         B.wb = v3(0.f, 0.f, 0.f);
         nstep = 0;
+#pragma unroll 1
+        for (int j = 0; j < 12; ++j) {     // the hinges restart from qpos0 (+ jitter): park them where the write-back reads them
+            const KLink &Lk = M->link[j];
+            lds[LQ(j) * 64 + lane] = reset_hinge(M->qpos0[7 + j], Lk.lo, Lk.hi, T->reset_joint_jitter, T->reset_flags, P.seed,
+                                                 P.env_index_base + (uint64_t)env, ep, j);
+        }
     }
     if (live) {
         P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
@@ -826,7 +847,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
         if (rst) P.st.episode[env] += 1;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            P.st.qpos[(7 + j) * n + env] = rst ? M->qpos0[7 + j] : lds[LQ(j) * 64 + lane];
+            P.st.qpos[(7 + j) * n + env] = lds[LQ(j) * 64 + lane];
             P.st.qvel[(6 + j) * n + env] = rst ? 0.f : lds[LQD(j) * 64 + lane];
             P.st.act[j * n + env] = rst ? 0.f : lds[LACT(j) * 64 + lane];
         }
@@ -1079,8 +1100,9 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
     if (rst) {
         B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
         B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+        const int ep = P.st.episode[env];          // read by every lane of the quad before its lead lane advances it below
         if (T->reset_flags & 1u) {
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)ep);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
             B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
@@ -1088,6 +1110,12 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         B.vw = v3(0.f, 0.f, 0.f);
         B.wb = v3(0.f, 0.f, 0.f);
         nstep = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const KLink &Lk = link_of<BAKED>(C, k, i);
+            L.q[i] = reset_hinge(C.qpos0[7 + (BAKED ? i : 3 * k + i)], Lk.lo, Lk.hi, T->reset_joint_jitter, T->reset_flags, P.seed,
+                                 P.env_index_base + (uint64_t)env, ep, 3 * k + i);
+        }
     }
     if (lead) {
         P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
@@ -1101,7 +1129,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int j = 3 * k + i;
-            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : L.q[i];
+            P.st.qpos[(7 + j) * n + env] = L.q[i];
             P.st.qvel[(6 + j) * n + env] = rst ? 0.f : L.qd[i];
             P.st.act[j * n + env] = rst ? 0.f : L.act[i];
             if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
@@ -1330,8 +1358,9 @@ __global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *
     if (rst) {
         B.pw = v3<float>(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
         B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+        const int ep = P.st.episode[env];          // read by both lanes of the pair before the lead lane advances it below
         if (T->reset_flags & 1u) {
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)ep);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
             B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
@@ -1339,6 +1368,13 @@ __global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *
         B.vw = v3<float>(0.f, 0.f, 0.f);
         B.wb = v3<float>(0.f, 0.f, 0.f);
         nstep = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const KLink &Lk = C.link[i];
+            const uint64_t ge = P.env_index_base + (uint64_t)env;
+            L.q[i].x = reset_hinge(C.qpos0[7 + i], Lk.lo, Lk.hi, T->reset_joint_jitter, T->reset_flags, P.seed, ge, ep, 3 * (2 * half) + i);
+            L.q[i].y = reset_hinge(C.qpos0[7 + i], Lk.lo, Lk.hi, T->reset_joint_jitter, T->reset_flags, P.seed, ge, ep, 3 * (2 * half + 1) + i);
+        }
     }
     if (lead) {
         P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
@@ -1354,7 +1390,7 @@ __global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int j = 3 * (2 * half + c) + i;
-                P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : (c == 0 ? L.q[i].x : L.q[i].y);
+                P.st.qpos[(7 + j) * n + env] = c == 0 ? L.q[i].x : L.q[i].y;
                 P.st.qvel[(6 + j) * n + env] = rst ? 0.f : (c == 0 ? L.qd[i].x : L.qd[i].y);
                 P.st.act[j * n + env] = rst ? 0.f : (c == 0 ? L.act[i].x : L.act[i].y);
                 if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[3 * c + i];
@@ -1364,16 +1400,20 @@ __global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *
 }
 
 // ------------------------------------------------------------------------------------------
-// reset (quadruped.py:115-139): mj_resetData, time = 0, ctrl = default; optional random yaw
+// reset (quadruped.py:115-139): mj_resetData, time = 0, ctrl = default; optional random yaw and hinge jitter
 // ------------------------------------------------------------------------------------------
 __global__ void qg_reset_kernel(const KModel *__restrict__ M, const KTask *__restrict__ T, KState st, int n, const uint8_t *mask,
                                 uint64_t seed, uint64_t env_index_base, uint32_t flags, int count_episode) {
     int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= n) return;
     if (mask && !mask[env]) return;
-    for (int j = 0; j < 19; ++j) st.qpos[j * n + env] = M->qpos0[j];
+    const int ep = st.episode[env];
+    for (int j = 0; j < 7; ++j) st.qpos[j * n + env] = M->qpos0[j];
+    for (int j = 0; j < 12; ++j)
+        st.qpos[(7 + j) * n + env] = reset_hinge(M->qpos0[7 + j], M->link[j].lo, M->link[j].hi, T->reset_joint_jitter, flags, seed,
+                                                 env_index_base + (uint64_t)env, ep, j);
     if (flags & 1u) {
-        float a = 6.283185307179586f * uniform24(seed, env_index_base + (uint64_t)env, (uint64_t)st.episode[env]);
+        float a = 6.283185307179586f * uniform24(seed, env_index_base + (uint64_t)env, (uint64_t)ep);
         float sn, cs;
         sincos_f(0.5f * a, sn, cs);
         st.qpos[3 * n + env] = cs; st.qpos[4 * n + env] = 0.f; st.qpos[5 * n + env] = 0.f; st.qpos[6 * n + env] = sn;

@@ -55,6 +55,7 @@ static inline int build_tables(const qg_model *m, const qg_task *t, KModel *km, 
             return fail(QG_ERR_ARG, "joint %d: the kernels assume the hinge axis is the link's +z (quadruped.xml:9)", b - 1);
     }
     if (t->frame_skip < 1) return fail(QG_ERR_ARG, "task.frame_skip must be >= 1");
+    if (!(t->reset_joint_jitter >= 0) || !(t->reset_joint_jitter < 10)) return fail(QG_ERR_ARG, "task.reset_joint_jitter must be in [0, 10) rad");
     if (t->obs_mode != QG_OBS_FULL && t->obs_mode != QG_OBS_IMU) return fail(QG_ERR_ARG, "task.obs_mode invalid");
 
     memset(km, 0, sizeof *km);
@@ -127,6 +128,7 @@ static inline int build_tables(const qg_model *m, const qg_task *t, KModel *km, 
     kt->auto_reset = t->auto_reset;
     kt->reset_flags = t->reset_flags;
     for (int i = 0; i < QG_NU; i++) kt->default_ctrl[i] = (float)t->default_ctrl[i];
+    kt->reset_joint_jitter = (float)t->reset_joint_jitter;
     return QG_OK;
 }
 

@@ -36,6 +36,10 @@ struct KWalkParams {
     float amp_target[12];
     float freq_target[12];
     int32_t auto_reset;
+    // on-device command sampler (control_inputs.py:74-115); cmd_sample = 0: commands only change through qg_walk_set_commands
+    int32_t cmd_sample;
+    uint32_t cmd_fixed;
+    float cmd_min_speed, cmd_max_speed, cmd_theta, cmd_alpha, cmd_speed;
 };
 
 struct KWalkState {
@@ -208,6 +212,30 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
         for (int j = 0; j < 12; ++j) S.prev_ctrl[j * n + env] = P.joint_centers[j];
         S.has_derive[env] = 0;
     }
+}
+
+// VelocityHeadingControls.sample (control_inputs.py:74-115) for the envs `select` marks (NULL = all): the command of the
+// episode that has just begun.  The physics reset has already advanced the env's episode counter, so the key of this
+// episode -- the one its reset yaw used -- is episode - 1.
+__global__ void qg_walk_command_kernel(KWalkParams P, KWalkState S, int n, const uint8_t *__restrict__ select, uint64_t seed,
+                                       uint64_t env_index_base, const int32_t *__restrict__ episode) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n) return;
+    if (select && !select[env]) return;
+    const uint64_t g = env_index_base + (uint64_t)env, c = (uint64_t)(episode[env] - 1);
+    const float pi = 3.14159265358979323846f;
+    float theta = P.cmd_theta, alpha = P.cmd_alpha, speed = P.cmd_speed;
+    if (!(P.cmd_fixed & 1u)) theta = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 0u) - 1.f);      // :97-100
+    if (!(P.cmd_fixed & 2u)) alpha = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 1u) - 1.f);      // :106-109
+    if (!(P.cmd_fixed & 4u)) speed = fmaf(P.cmd_max_speed - P.cmd_min_speed, uniform24s(seed, g, c, QG_STREAM_COMMAND + 2u), P.cmd_min_speed);   // :112-115
+    float st, ct, sa, ca;
+    sincosf(theta, &st, &ct);
+    sincosf(alpha, &sa, &ca);
+    const float vx = speed * ca, vy = speed * sa;          // set_velocity_speed_alpha (:45-51)
+    S.vel[env] = vx; S.vel[n + env] = vy;
+    S.head[env] = ct; S.head[n + env] = st;                // set_orientation (:29-36)
+    S.gvel[env] = ct * vx - st * vy;                       // :14-27
+    S.gvel[n + env] = st * vx + ct * vy;
 }
 
 // explicit (masked) episode reset of the walking state

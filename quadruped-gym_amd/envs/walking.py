@@ -50,7 +50,8 @@ class WalkingQuadrupedVecEnv:
     reward_keys = REWARD_KEYS
 
     def __init__(self, num_envs, settling_time=0, random_controls=False, random_init=False, reset_options=None,
-                 model_path="builtin", max_time=10.0, frame_skip=4, device=0, env_index_base=0, seed=0, walk_params=None):
+                 model_path="builtin", max_time=10.0, frame_skip=4, device=0, env_index_base=0, seed=0, walk_params=None,
+                 device_commands=False):
         qg_model, layout = load_model(model_path)
         self.model = ModelView(qg_model, layout)
         self.num_envs = int(num_envs)
@@ -73,6 +74,13 @@ class WalkingQuadrupedVecEnv:
         self._w = h
         self._seed = int(seed)
         self._flags = task.reset_flags
+        # random_controls (walking_quad.py:121-122).  device_commands=False: commands are redrawn on the host with
+        # np.random.uniform in the reference's order (VelocityHeadingControls.sample); True: on the GPU, inside reset and
+        # the step's auto-reset, from the env's own counter-based stream -- rollouts through step_tensor never touch the host.
+        self.device_commands = bool(device_commands) and bool(random_controls)
+        if self.device_commands:
+            sampler = _abi.QgCommandSampler.from_options(reset_options)
+            check(self._lib.qg_walk_set_command_sampler(self._w, C.byref(sampler)), "qg_walk_set_command_sampler")
         self.action_space = Box(low=-1.0, high=1.0, shape=(12,), dtype=np.float32)
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(33,), dtype=np.float32)
         self.velocity = np.zeros((self.num_envs, 2), np.float32)
@@ -86,7 +94,14 @@ class WalkingQuadrupedVecEnv:
         self.heading[:] = np.asarray(heading_xy, np.float32).reshape(self.num_envs, 2)
         check(self._lib.qg_walk_set_commands(self._w, self.velocity.ctypes.data, self.heading.ctypes.data), "qg_walk_set_commands")
 
+    def commands(self):
+        """``(velocity_xy, heading_xy)`` as they stand on the device, ``[num_envs, 2]`` each."""
+        check(self._lib.qg_walk_get_commands(self._w, self.velocity.ctypes.data, self.heading.ctypes.data), "qg_walk_get_commands")
+        return self.velocity, self.heading
+
     def _resample(self, idx):
+        if self.device_commands:          # already redrawn on the device by the reset / auto-reset itself
+            return
         for i in idx:
             v, hd = sample_command(self.reset_options)
             self.velocity[i], self.heading[i] = v, hd

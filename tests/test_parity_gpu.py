@@ -208,6 +208,62 @@ def test_random_yaw_reset_matches_oracle_stream(oracle):
     sim.close()
 
 
+def test_joint_jitter_reset_matches_oracle_stream(oracle):
+    """QG_RESET_JOINT_JITTER (the reference's open 'randomize starting pose, joints' item, TODO.md:8): every hinge starts at
+    qpos0 + jitter * U(-1, 1) from its own stream of the (seed, global env index, episode) key, kept inside its range."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n, base = 100, 5000
+    task = _abi.default_task()
+    task.reset_joint_jitter = 0.25
+    sim = BatchedSim(n, task=task, env_index_base=base)
+    flags = _abi.RESET_RANDOM_YAW | _abi.RESET_JOINT_JITTER
+    for episode in range(2):                      # the explicit reset advances the per-env episode counter
+        sim.reset(seed=77, flags=flags)
+        qpos = sim.get_state()[0]
+        ot = oracle.default_task()
+        ot.reset_joint_jitter = 0.25
+        want = np.array([np.array(oracle.reset(oracle.default_model(), ot, seed=77, env_index=base + i, counter=episode,
+                                               flags=flags).qpos[:]) for i in range(n)])
+        assert np.allclose(qpos, want, atol=3e-7)
+        lo = np.array([r[0] for r in sim.model.jnt_range]); hi = np.array([r[1] for r in sim.model.jnt_range])
+        assert (qpos[:, 7:] >= lo - 1e-6).all() and (qpos[:, 7:] <= hi + 1e-6).all()
+        assert np.ptp(qpos[:, 9]) > 0.3          # the draw really spreads (shin hinge, range wider than the jitter)
+    sim.reset(seed=77, flags=0)
+    assert np.allclose(sim.get_state()[0], np.array(sim.model.qpos0[:], np.float32)[None])
+    sim.close()
+
+
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+def test_auto_reset_draws_match_oracle_stream(oracle, mapping):
+    """The in-kernel auto-reset of each mapping applies the same yaw + hinge-jitter draws as the oracle's reset with the env's
+    episode counter."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n, base = 70, 300
+    task = _abi.default_task()
+    task.max_time = 0.016          # 8 substeps: every second env-step ends the episode
+    task.auto_reset = 1
+    task.reset_joint_jitter = 0.2
+    flags = _abi.RESET_RANDOM_YAW | _abi.RESET_JOINT_JITTER
+    task.reset_flags = flags
+    sim = BatchedSim(n, task=task, env_index_base=base)
+    sim.set_mapping(MAPPINGS[mapping])
+    sim.reset(seed=5, flags=flags)                # episode 0 draws
+    ot = oracle.default_task()
+    ot.reset_joint_jitter = 0.2
+    a = np.zeros((n, 12), np.float32)
+    for episode in (1, 2):
+        d = None
+        for _ in range(2):
+            d = sim.step(a)[2]
+        assert d.all()
+        qpos, qvel, act, _, nstep = sim.get_state()
+        want = np.array([np.array(oracle.reset(oracle.default_model(), ot, seed=5, env_index=base + i, counter=episode,
+                                               flags=flags).qpos[:]) for i in range(n)])
+        assert np.allclose(qpos, want, atol=3e-7), np.abs(qpos - want).max()
+        assert not qvel.any() and not act.any() and not nstep.any()
+    sim.close()
+
+
 @pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 def test_time_limit_terminates_and_auto_reset(mapping):
     """`time >= max_time` is reported as terminated on the exact substep the f64-accumulated clock
@@ -339,13 +395,13 @@ def test_sharding_does_not_change_results(mapping):
     task = _abi.default_task()
     task.auto_reset = 1
     task.max_time = 0.04
-    task.reset_flags = _abi.RESET_RANDOM_YAW
+    task.reset_flags = _abi.RESET_RANDOM_YAW | _abi.RESET_JOINT_JITTER
     rng = np.random.default_rng(11)
     whole = BatchedSim(256, task=task)
     parts = [BatchedSim(128, task=task, env_index_base=0), BatchedSim(128, task=task, env_index_base=128)]
     for s in [whole] + parts:
         s.set_mapping(MAPPINGS[mapping])
-        s.reset(seed=9, flags=_abi.RESET_RANDOM_YAW)
+        s.reset(seed=9, flags=_abi.RESET_RANDOM_YAW | _abi.RESET_JOINT_JITTER)
     for k in range(12):
         a = rng.uniform(-1, 1, (256, 12)).astype(np.float32)
         ow = whole.step(a)

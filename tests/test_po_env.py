@@ -82,3 +82,31 @@ def test_po_single_env_facade():
     assert obs.shape == (260,) and np.allclose(obs[-15:-3], [0, 0, -0.5] * 4)    # settling: joint centres applied
     assert np.allclose(obs[-3:], [0.3, 0.0, 0.0], atol=1e-6)
     env.close()
+
+
+@pytest.mark.gpu
+def test_po_frames_show_the_command_in_force_with_device_sampler():
+    """po_walking_quad.py:48-69 with commands redrawn on the device: the terminal frame and the reset frame of an episode
+    still show the command that was in force (the reference builds both before ``control_inputs.sample`` runs,
+    walking_quad.py:103,121-122); the first frame of the next episode shows the new one."""
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
+    n = 16
+    env = POWalkingQuadrupedVecEnv(n, obs_window=1, max_time=0.016, random_controls=True, device_commands=True, seed=3,
+                                   reset_options={"min_speed": 0.5, "max_speed": 1.5})
+    first = env.reset()
+    assert not first[:, 23:26].any()                      # nothing had been drawn when the reset frame was built
+    v0, h0 = (x.copy() for x in env.commands())
+    assert (np.linalg.norm(v0, axis=1) >= 0.5 - 1e-6).all()
+    a = np.zeros((n, 12), np.float32)
+    o1 = env.step(a)[0]
+    assert np.allclose(o1[:, 23:25], v0, atol=1e-6) and np.allclose(o1[:, 25], np.arctan2(h0[:, 1], h0[:, 0]), atol=1e-5)
+    o2, _, dones, infos = env.step(a)                     # 8 substeps: episode over, auto-reset, new command drawn
+    assert dones.all()
+    term = np.stack([i["terminal_observation"] for i in infos])
+    assert np.allclose(term[:, 23:25], v0, atol=1e-6)     # terminal frame: old command
+    assert np.allclose(o2[:, 23:25], v0, atol=1e-6)       # reset frame: still the old command (reference quirk)
+    v1, h1 = (x.copy() for x in env.commands())
+    assert np.abs(v1 - v0).max() > 1e-3
+    o3 = env.step(a)[0]
+    assert np.allclose(o3[:, 23:25], v1, atol=1e-6) and np.allclose(o3[:, 25], np.arctan2(h1[:, 1], h1[:, 0]), atol=1e-5)
+    env.close()

@@ -93,6 +93,38 @@ def test_settling_mask_flip_and_auto_reset():
     env.close(); env2.close()
 
 
+def test_device_command_sampler_matches_oracle_stream():
+    """random_controls on the device: at reset and at every auto-reset each env draws a new command with the
+    semantics of VelocityHeadingControls.sample(options) (control_inputs.py:74-115) from its own (seed, global env index,
+    episode) stream; the oracle's Controls.sample fed with the same stream must give the same velocity / heading."""
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    from oracle.walking_oracle import Controls, sample_keyed
+    n, base, seed = 48, 700, 31
+    for options in ({"min_speed": 0.2, "max_speed": 0.8}, {"fixed_heading_angle": 0.5, "max_speed": 2.0},
+                    {"fixed_velocity_angle": -1.0, "fixed_speed": 0.3}, None):
+        env = WalkingQuadrupedVecEnv(n, max_time=0.016, random_init=True, random_controls=True, reset_options=options,
+                                     env_index_base=base, seed=seed, device_commands=True)
+        env.reset()                                           # episode 0
+        a = np.zeros((n, 12), np.float32)
+        for episode in range(3):
+            want = Controls(n)
+            for i in range(n):
+                sample_keyed(want, i, options, seed, base + i, episode)
+            v, h = env.commands()
+            assert np.allclose(v, want.velocity[:, :2], atol=2e-6) and np.allclose(h, want.heading[:, :2], atol=2e-6)
+            d = None
+            for _ in range(2):                                # 8 substeps: the second env-step ends the episode
+                d = env.step(a)[2]
+            assert d.all()
+        env.close()
+    # without random_controls nothing is drawn
+    env = WalkingQuadrupedVecEnv(4, device_commands=True)
+    env.reset()
+    v, h = env.commands()
+    assert not v.any() and not h.any()
+    env.close()
+
+
 def test_single_env_facade_has_reference_signature():
     import inspect
     from quadruped_gym_amd.envs.walking import REWARD_KEYS, WalkingQuadrupedEnv
