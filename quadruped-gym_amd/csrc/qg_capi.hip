@@ -261,6 +261,13 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         hipLaunchKernelGGL(qg_step_kernel<false>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_step_kernel launch: %s", hipGetErrorString(e));
+    if (s->task.auto_reset && (s->task.reset_flags & QG_RESET_JOINT_JITTER)) {     // start-pose randomisation of the envs just auto-reset
+        const int total = 12 * s->n, threads = 256;
+        hipLaunchKernelGGL(qg_jitter_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, stream, s->d_model, s->d_task, s->st, s->n,
+                           (const uint8_t *)d_done, (const float *)d_packed, s->obs_dim + 2, s->seed, s->env_index_base);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_jitter_kernel launch: %s", hipGetErrorString(e));
+    }
     return QG_OK;
 }
 
