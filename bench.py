@@ -365,12 +365,12 @@ def main():
                                  "~35 k VALU lane-instructions; the HBM fraction is small by construction"},
         }
         if valu:
-            # issue-rate view of the same launch: wave-instructions/s against 1024 SIMDs x (2.4 GHz / 4 cycles per wave64 VALU
-            # instruction -- the measured issue rate of v_fma_f32 and of v_pk_fma_f32, tools/ubench/valu_rate.hip)
+            # issue-rate view of the same launch: wave-instructions/s against 1024 SIMDs x (2.4 GHz / 2 cycles per wave64 VALU
+            # instruction: SIMD-32; measured 2.2-2.5 with >= 2 resident waves, >= 4.5 for a lone wave, tools/ubench/valu_rate.hip)
             waves = -(-n // MAP_ENVS_PER_WAVE[sim.mapping])
             rate = valu * waves / (kernel_ms * 1e-3)
             line["roofline"]["valu_issue"] = {"insts_per_wave": valu, "waves": waves, "achieved_ginst_s": rate / 1e9,
-                                              "peak_ginst_s": 1024 * 2.4 / 4, "frac": rate / (1024 * 0.6e9)}
+                                              "peak_ginst_s": 1024 * 2.4 / 2, "frac": rate / (1024 * 1.2e9)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)
         print(json.dumps(line), flush=True)

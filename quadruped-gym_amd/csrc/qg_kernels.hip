@@ -855,7 +855,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
 // block (Schur complements, 33 numbers) are summed over the quad with DPP quad_perm moves --
 // no LDS, no run-time indexed arrays.  A wave carries 16 envs, so 4096 envs fill 256 waves
 // instead of 64: at batch sizes that cannot fill the chip with one env per lane this cuts the
-// instructions per wave (= the time, a lone wave issues one VALU instruction per 4 cycles) ~3.5x.
+// instructions per wave (= the time, a lone wave issues one VALU instruction per ~4.5-5 cycles) ~3.5x.
 // BAKED variant: the compiled-in robot, whose legs are quarter-turn copies of one another (constants become literals).
 // Generic variant: any model numbers; the tables are staged in LDS and each lane reads its own leg's rows.
 // ------------------------------------------------------------------------------------------
@@ -1125,9 +1125,9 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
 // 2h+1 as the two components of f2 quantities, so every fma / mul / add of the leg physics is ONE v_pk_* instruction for
 // both legs.  32 envs per wave.  Base prelude, FRAME terms, 6x6 solve and base integration are scalar and redundant in the
 // two lanes; leg terms are summed over the two components (a scalar add of the two halves of the register pair) and over the
-// lane pair (one DPP add).  Per env this needs ~1.9x fewer instruction issue slots than one leg per lane, which is what
-// bounds large batches (a SIMD retires one non-packed wave64 FP32 instruction per 4 cycles however many waves it holds);
-// at batch sizes that leave most SIMDs idle the quad mapping's shorter per-wave stream is faster.  Compiled-in robot only.
+// lane pair (one DPP add).  Per env this issues 0.59x the instructions of one leg per lane.  v_pk_*_f32 is half rate on gfx950
+// (tools/ubench/valu_rate.hip), so this pays only where a wave has its SIMD to itself anyway -- a lone wave issues at most
+// every ~4.5 cycles, packed or not: grids of 16-32 Ki envs and, by a smaller margin, >= 56 Ki.  Compiled-in robot only.
 // ------------------------------------------------------------------------------------------
 DEV float pair_sum(float x) { return x + dpp_quad<0xB1>(x); }      // quad_perm [1,0,3,2]: the other lane of the pair
 DEV float hsum(f2 v) { return v.x + v.y; }

@@ -6,7 +6,8 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define ITERS 2048
 #define REP 8      // 8 x 8 = 64 fma per loop iteration
-template <int MODE> __global__ __launch_bounds__(64) void k(float *out, float a, float b) {
+template <int MODE> __global__ __launch_bounds__(64) void k(float *out, float a, float b, unsigned long long *clk) {
+    unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
     float x[8]; f2 y[8];
     for (int i = 0; i < 8; i++) { x[i] = threadIdx.x * 0.001f + i; y[i] = f2{x[i], x[i] + 1.f}; }
     f2 a2 = {a, a * 1.0001f}, b2 = {b, b * 0.9999f};
@@ -27,6 +28,26 @@ template <int MODE> __global__ __launch_bounds__(64) void k(float *out, float a,
             for (int r = 0; r < REP; r++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) y[0] = __builtin_elementwise_fma(y[0], a2, b2);
+        } else if (MODE == 4) {   // 8 independent v_mul_f32 by a literal
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = x[i] * 1.0001f;
+        } else if (MODE == 5) {   // 8 independent v_add_f32 of an inline constant
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = x[i] + 0.5f;
+        } else if (MODE == 6) {   // 8 independent fma with one VGPR and two literals (v_fmaak / v_fmamk)
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = __builtin_fmaf(x[i], 0.9999f, 0.0001f);
+        } else if (MODE == 7) {   // 8 independent fma with three VGPR sources
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = __builtin_fmaf(x[i], x[(i + 1) & 7], x[(i + 2) & 7]);
         } else {                  // 8 independent packed chains
 #pragma unroll
             for (int r = 0; r < REP; r++)
@@ -37,27 +58,36 @@ template <int MODE> __global__ __launch_bounds__(64) void k(float *out, float a,
     float s = 0;
     for (int i = 0; i < 8; i++) s += x[i] + y[i].x + y[i].y;
     out[blockIdx.x * 64 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - c0; clk[1] = wall_clock64() - r0; }
 }
 template <int MODE> void run(const char *name, int waves_per_simd, float *d) {
+    static unsigned long long *clk = nullptr; if (!clk) hipMalloc(&clk, 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     int blocks = 1024 * waves_per_simd;
-    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 0.999f, 0.001f);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 0.999f, 0.001f, clk);
     hipEventRecord(e0);
-    for (int q = 0; q < 5; q++) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 0.999f, 0.001f);
+    for (int q = 0; q < 5; q++) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d, 0.999f, 0.001f, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     double inst = (double)ITERS * 8 * REP;                          // fma instructions per wave
     double cyc = ms * 1e-3 * 2.4e9;                           // at the 2.4 GHz peak clock
+    unsigned long long h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    // wave 0's own counters: s_memtime ticks and the 100 MHz constant clock over its whole run
+    printf("   [wave 0: %llu s_memtime ticks in %.1f us -> %.0f MHz tick rate, %.2f ticks per fma]\n", h[0], h[1] / 100.0, h[0] / (h[1] / 100.0), (double)h[0] / inst);
     printf("%-28s waves/SIMD %d  %7.3f ms  %.2f cycles per fma per wave, %.2f per SIMD issue slot\n", name, waves_per_simd, ms, cyc / inst,
            cyc / inst / waves_per_simd);
 }
 int main() {
-    float *d; hipMalloc(&d, 4096 * 64 * 4);
-    for (int w = 1; w <= 2; w++) {
+    float *d; hipMalloc(&d, 8192 * 64 * 4);
+    for (int w = 1; w <= 4; w *= 2) {
         run<0>("v_fma_f32 dependent", w, d);
         run<1>("v_fma_f32 8 independent", w, d);
         run<2>("v_pk_fma_f32 dependent", w, d);
         run<3>("v_pk_fma_f32 8 independent", w, d);
+        run<4>("v_mul_f32 literal 8 indep", w, d);
+        run<5>("v_add_f32 inline 8 indep", w, d);
+        run<6>("v_fmaak 2 literals 8 indep", w, d);
+        run<7>("v_fma_f32 3 VGPRs 8 indep", w, d);
     }
     return 0;
 }
