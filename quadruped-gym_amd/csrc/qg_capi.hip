@@ -252,8 +252,9 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
             if (one_wave) hipLaunchKernelGGL((qg_step_kernel_quad<1, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
             else hipLaunchKernelGGL((qg_step_kernel_quad<2, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
         } else {
-            if (one_wave) hipLaunchKernelGGL((qg_step_kernel_quad<1, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-            else hipLaunchKernelGGL((qg_step_kernel_quad<2, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+            // tables in LDS: the 256-register cap spills 888 B per lane and measured 2x slower at every grid size (363 vs 741 us
+            // at 262 144 envs), so any other robot runs the one-wave-per-SIMD form throughout
+            hipLaunchKernelGGL((qg_step_kernel_quad<1, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
         }
     } else if (s->baked)
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
