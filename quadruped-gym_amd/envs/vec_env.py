@@ -98,16 +98,16 @@ class QuadrupedVecEnv:
 
     def step_wait(self):
         obs, rew, done, comps = self._sim.step(self._actions, want_components=True)
-        infos = []
         names = _REWARD_BUILTINS
-        for i in range(self.num_envs):
-            info = {"reward_components": {names[k]: float(comps[i, k]) for k in range(3)}}
-            for k in range(3):
-                info[names[k]] = float(comps[i, k])
-            if done[i]:
-                info["terminal_observation"] = obs[i].copy()
-                info["TimeLimit.truncated"] = False       # the reference reports the time limit as `terminated`
+        infos = []
+        for row in comps.tolist():                          # one C-level conversion; per-element float() costs 4x as much
+            rc = dict(zip(names, row))
+            info = dict(rc)
+            info["reward_components"] = rc
             infos.append(info)
+        for i in np.nonzero(done)[0]:
+            infos[i]["terminal_observation"] = obs[i].copy()
+            infos[i]["TimeLimit.truncated"] = False         # the reference reports the time limit as `terminated`
         obs = obs.copy()
         obs[done] = 0.0                                    # envs that finished were reset: their next obs is the reset obs
         return obs, rew, done, infos

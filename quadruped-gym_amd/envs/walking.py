@@ -129,13 +129,10 @@ class WalkingQuadrupedVecEnv:
         check(self._lib.qg_walk_step(self._w, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, comps.ctypes.data),
               "qg_walk_step")
         dones = done.astype(bool)
-        infos = []
-        for i in range(n):
-            info = {k: float(comps[i, j]) for j, k in enumerate(REWARD_KEYS)}
-            if dones[i]:
-                info["terminal_observation"] = obs[i].copy()
-                info["TimeLimit.truncated"] = False
-            infos.append(info)
+        infos = [dict(zip(REWARD_KEYS, row)) for row in comps.tolist()]
+        for i in np.nonzero(dones)[0]:
+            infos[i]["terminal_observation"] = obs[i].copy()
+            infos[i]["TimeLimit.truncated"] = False
         if dones.any():
             obs = obs.copy()
             obs[dones] = 0.0
@@ -271,13 +268,10 @@ class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
         check(self._lib.qg_po_step(self._po, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, comps.ctypes.data,
                                    term.ctypes.data), "qg_po_step")
         dones = done.astype(bool)
-        infos = []
-        for i in range(n):
-            info = {k: float(comps[i, j]) for j, k in enumerate(REWARD_KEYS)}
-            if dones[i]:
-                info["terminal_observation"] = term[i].copy()
-                info["TimeLimit.truncated"] = False
-            infos.append(info)
+        infos = [dict(zip(REWARD_KEYS, row)) for row in comps.tolist()]
+        for i in np.nonzero(dones)[0]:
+            infos[i]["terminal_observation"] = term[i].copy()
+            infos[i]["TimeLimit.truncated"] = False
         if dones.any() and self.random_controls:
             self._resample(np.nonzero(dones)[0])
         self.last_components = comps
