@@ -687,7 +687,8 @@ extern "C" int qg_walk_reset(qg_walk *w, const uint8_t *mask, uint64_t seed, uin
 
 // pre + physics + post.  The commands of auto-reset envs are redrawn by the caller AFTER everything that still reads the old
 // ones (the partially observable pack) has been launched.
-static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream) {
+static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream,
+                          bool po_follows) {
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     hipStream_t st = (hipStream_t)stream;
@@ -699,16 +700,15 @@ static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *r
     int rc = launch_step(s, w->st.eff_actions, obs, reward, done, nullptr, nullptr, st);
     if (rc != QG_OK) return rc;
     hipLaunchKernelGGL(qg_walk_post_kernel, dim3((s->n + threads - 1) / threads), dim3(threads), 0, st, w->kp, w->st, s->n, (const float *)obs,
-                       (const uint8_t *)done, reward, components);
+                       (const uint8_t *)done, reward, components, (w->kp.cmd_sample && !po_follows) ? 1 : 0, s->seed, s->env_index_base,
+                       (const int32_t *)s->st.episode);
     HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
     return QG_OK;
 }
 
 extern "C" int qg_walk_step_device(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream) {
     if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step_device: null argument");
-    int rc = walk_step_core(w, actions, obs, reward, done, components, stream);
-    if (rc != QG_OK) return rc;
-    return w->kp.auto_reset ? walk_sample_commands(w, done, (hipStream_t)stream) : QG_OK;
+    return walk_step_core(w, actions, obs, reward, done, components, stream, false);
 }
 
 extern "C" int qg_walk_step(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components) {
@@ -758,7 +758,7 @@ struct qg_po {
 extern "C" int qg_po_destroy(qg_po *p) {
     if (!p) return QG_OK;
     (void)hipSetDevice(p->walk->sim->device);
-    void *ptrs[] = {p->st.orient, p->st.alias, p->st.nstep, p->st.stack, p->d_obs33, p->d_out, p->d_term};
+    void *ptrs[] = {p->st.orient, p->st.alias, p->st.nstep, p->st.stack, p->st.head, p->d_obs33, p->d_out, p->d_term};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -806,12 +806,14 @@ extern "C" int qg_po_create(qg_walk *w, int32_t obs_window, qg_po **out) {
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.alias, n);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.nstep, n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.stack, n * width * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->st.head, n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_obs33, n * QG_NSENSOR * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_out, n * width * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_term, n * width * 4);
     if (e == hipSuccess) e = hipMemset(p->st.alias, 0, n);
     if (e == hipSuccess) e = hipMemset(p->st.nstep, 0, n * 4);
     if (e == hipSuccess) e = hipMemset(p->st.stack, 0, n * width * 4);
+    if (e == hipSuccess) e = hipMemset(p->st.head, 0, n * 4);
     if (e == hipSuccess) {                                           // computed_orientation = [1, 0, 0, 0] (:19)
         float *h = new float[4 * n];
         for (size_t i = 0; i < n; i++) { h[i] = 1.f; h[n + i] = h[2 * n + i] = h[3 * n + i] = 0.f; }
@@ -843,14 +845,14 @@ extern "C" int qg_po_step_device(qg_po *p, const float *actions, float *obs, flo
     if (!p || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_po_step_device: null argument");
     qg_walk *w = p->walk;
     qg_sim *s = w->sim;
-    int rc = walk_step_core(w, actions, p->d_obs33, reward, done, components, stream);
+    int rc = walk_step_core(w, actions, p->d_obs33, reward, done, components, stream, true);
     if (rc != QG_OK) return rc;
-    int threads = 128, blocks = (s->n + threads - 1) / threads;
-    hipLaunchKernelGGL(qg_po_frame_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, p->kp, p->st, s->n, (const float *)p->d_obs33,
-                       (const float *)w->st.eff_actions, (const float *)s->st.qpos, (const float *)w->st.vel, (const float *)w->st.head,
-                       (const uint8_t *)done, obs, terminal_obs);
+    int blocks = (s->n + QG_PO_ENVS - 1) / QG_PO_ENVS;
+    hipLaunchKernelGGL(qg_po_frame_kernel, dim3(blocks), dim3(QG_PO_THREADS), 0, (hipStream_t)stream, p->kp, p->st, s->n, (const float *)p->d_obs33,
+                       (const float *)w->st.eff_actions, (const float *)s->st.qpos, w->kp, w->st, (const uint8_t *)done, obs, terminal_obs,
+                       w->kp.cmd_sample ? 1 : 0, s->seed, s->env_index_base, (const int32_t *)s->st.episode);
     HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
-    return w->kp.auto_reset ? walk_sample_commands(w, done, (hipStream_t)stream) : QG_OK;   // after the frames that show the old command
+    return QG_OK;
 }
 
 extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *reward, uint8_t *done, float *components, float *terminal_obs) {

@@ -134,9 +134,32 @@ __global__ void qg_walk_pre_kernel(KWalkParams P, KWalkState S, int n, const flo
     S.a_est[t] = P.ema_alpha * S.a_est[t] + (1.f - P.ema_alpha) * (mx - mn);       // :129
 }
 
-// one thread per env
+// VelocityHeadingControls.sample (control_inputs.py:74-115) for one env: the command of the episode that has just begun.
+// The physics reset has already advanced the env's episode counter, so the key of this episode -- the one its reset yaw
+// used -- is episode - 1.
+__device__ __forceinline__ void walk_sample_command(const KWalkParams &P, const KWalkState &S, int n, int env, uint64_t seed,
+                                                    uint64_t env_index_base, int episode_now) {
+    const uint64_t g = env_index_base + (uint64_t)env, c = (uint64_t)(episode_now - 1);
+    const float pi = 3.14159265358979323846f;
+    float theta = P.cmd_theta, alpha = P.cmd_alpha, speed = P.cmd_speed;
+    if (!(P.cmd_fixed & 1u)) theta = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 0u) - 1.f);      // :97-100
+    if (!(P.cmd_fixed & 2u)) alpha = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 1u) - 1.f);      // :106-109
+    if (!(P.cmd_fixed & 4u)) speed = fmaf(P.cmd_max_speed - P.cmd_min_speed, uniform24s(seed, g, c, QG_STREAM_COMMAND + 2u), P.cmd_min_speed);   // :112-115
+    float st, ct, sa, ca;
+    sincosf(theta, &st, &ct);
+    sincosf(alpha, &sa, &ca);
+    const float vx = speed * ca, vy = speed * sa;          // set_velocity_speed_alpha (:45-51)
+    S.vel[env] = vx; S.vel[n + env] = vy;
+    S.head[env] = ct; S.head[n + env] = st;                // set_orientation (:29-36)
+    S.gvel[env] = ct * vx - st * vy;                       // :14-27
+    S.gvel[n + env] = st * vx + ct * vy;
+}
+
+// one thread per env.  `sample_here`: redraw the command of the envs the step has auto-reset (random_controls on the device);
+// off when a partially observable pack follows, which still has to show the old command and redraws afterwards itself.
 __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const float *__restrict__ obs /* [n][33] */,
-                                    const uint8_t *__restrict__ done, float *__restrict__ reward, float *__restrict__ comps /* [n][11] or NULL */) {
+                                    const uint8_t *__restrict__ done, float *__restrict__ reward, float *__restrict__ comps /* [n][11] or NULL */,
+                                    int sample_here, uint64_t seed, uint64_t env_index_base, const int32_t *__restrict__ episode) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= n) return;
     const float *s = obs + (size_t)env * 33;
@@ -211,31 +234,17 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
 #pragma unroll
         for (int j = 0; j < 12; ++j) S.prev_ctrl[j * n + env] = P.joint_centers[j];
         S.has_derive[env] = 0;
+        if (sample_here) walk_sample_command(P, S, n, env, seed, env_index_base, episode[env]);     // walking_quad.py:121-122
     }
 }
 
-// VelocityHeadingControls.sample (control_inputs.py:74-115) for the envs `select` marks (NULL = all): the command of the
-// episode that has just begun.  The physics reset has already advanced the env's episode counter, so the key of this
-// episode -- the one its reset yaw used -- is episode - 1.
+// the same draw for the envs `select` marks (NULL = all), as its own launch: explicit resets
 __global__ void qg_walk_command_kernel(KWalkParams P, KWalkState S, int n, const uint8_t *__restrict__ select, uint64_t seed,
                                        uint64_t env_index_base, const int32_t *__restrict__ episode) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
     if (env >= n) return;
     if (select && !select[env]) return;
-    const uint64_t g = env_index_base + (uint64_t)env, c = (uint64_t)(episode[env] - 1);
-    const float pi = 3.14159265358979323846f;
-    float theta = P.cmd_theta, alpha = P.cmd_alpha, speed = P.cmd_speed;
-    if (!(P.cmd_fixed & 1u)) theta = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 0u) - 1.f);      // :97-100
-    if (!(P.cmd_fixed & 2u)) alpha = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 1u) - 1.f);      // :106-109
-    if (!(P.cmd_fixed & 4u)) speed = fmaf(P.cmd_max_speed - P.cmd_min_speed, uniform24s(seed, g, c, QG_STREAM_COMMAND + 2u), P.cmd_min_speed);   // :112-115
-    float st, ct, sa, ca;
-    sincosf(theta, &st, &ct);
-    sincosf(alpha, &sa, &ca);
-    const float vx = speed * ca, vy = speed * sa;          // set_velocity_speed_alpha (:45-51)
-    S.vel[env] = vx; S.vel[n + env] = vy;
-    S.head[env] = ct; S.head[n + env] = st;                // set_orientation (:29-36)
-    S.gvel[env] = ct * vx - st * vy;                       // :14-27
-    S.gvel[n + env] = st * vx + ct * vy;
+    walk_sample_command(P, S, n, env, seed, env_index_base, episode[env]);
 }
 
 // explicit (masked) episode reset of the walking state

@@ -277,6 +277,15 @@ class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
         self.last_components = comps
         return obs, rew, dones, infos
 
+    def step_tensor(self, actions, obs, reward, done, components=None, terminal_obs=None, stream=None):
+        """Zero-copy step on CUDA tensors: ``actions`` float32 ``[N,12]`` -> ``obs`` float32 ``[N, 26 * obs_window]`` (the
+        stacked frames; rows of envs that finished already hold the reset stack), ``reward`` ``[N]``, ``done`` uint8
+        ``[N]``, optionally ``components`` ``[N,11]`` and ``terminal_obs`` (the stack each finished env ended with)."""
+        check(self._lib.qg_po_step_device(self._po, actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), done.data_ptr(),
+                                          components.data_ptr() if components is not None else None,
+                                          terminal_obs.data_ptr() if terminal_obs is not None else None,
+                                          self._sim._stream_ptr(stream)), "qg_po_step_device")
+
     def close(self):
         if getattr(self, "_po", None):
             self._lib.qg_po_destroy(self._po)

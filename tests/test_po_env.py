@@ -110,3 +110,30 @@ def test_po_frames_show_the_command_in_force_with_device_sampler():
     o3 = env.step(a)[0]
     assert np.allclose(o3[:, 23:25], v1, atol=1e-6) and np.allclose(o3[:, 25], np.arctan2(h1[:, 1], h1[:, 0]), atol=1e-5)
     env.close()
+
+
+@pytest.mark.gpu
+def test_po_step_tensor_equals_host_step():
+    """The zero-copy entry point (device tensors, caller's stream) returns what the NumPy path returns."""
+    import torch
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
+    n, w = 24, 3
+    a_env = POWalkingQuadrupedVecEnv(n, obs_window=w, max_time=0.05)
+    b_env = POWalkingQuadrupedVecEnv(n, obs_window=w, max_time=0.05)
+    a_env.reset(); b_env.reset()
+    v = np.tile([[0.3, 0.1]], (n, 1)); h = np.tile([[1.0, 0.0]], (n, 1))
+    a_env.set_commands(v, h); b_env.set_commands(v, h)
+    dev = torch.device("cuda:0")
+    obs = torch.empty((n, 26 * w), device=dev); rew = torch.empty(n, device=dev)
+    done = torch.empty(n, device=dev, dtype=torch.uint8); comps = torch.empty((n, 11), device=dev); term = torch.empty((n, 26 * w), device=dev)
+    rng = np.random.default_rng(4)
+    for k in range(9):                                      # crosses the 0.05 s time limit: auto-reset inside the step
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        o, r, d, infos = a_env.step(a)
+        b_env.step_tensor(torch.from_numpy(a).to(dev), obs, rew, done, comps, term)
+        torch.cuda.synchronize()
+        assert np.array_equal(o, obs.cpu().numpy()) and np.array_equal(r, rew.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(d, done.cpu().numpy().astype(bool))
+        for i in np.nonzero(d)[0]:
+            assert np.array_equal(infos[i]["terminal_observation"], term[i].cpu().numpy())
+    a_env.close(); b_env.close()
