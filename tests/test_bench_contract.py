@@ -27,3 +27,57 @@ def test_traffic_index_is_consistent():
     assert os.path.exists(os.path.join(ROOT, ent["source"]))
     assert abs(ent["write"] - 340 * 4096) < 0.001 * 340 * 4096   # writes match the algorithmic 340 B per env (plus the rare reset bookkeeping)
     assert 0.9 * 588 * 4096 < ent["hbm_bytes_per_launch"] < 2.0 * 588 * 4096
+
+
+import json
+import socket
+import subprocess
+import sys
+
+import pytest
+
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line_on_one_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--cpu-seconds", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["steps"] == 200 and d["warmup"] == 20 and d["higher_is_better"] is True
+    assert d["metric"] == "env_steps_per_sec" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"] == "qg_step_kernel_quad"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["state_finite"] is True
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 code path of bench.py (rank-local shards, per-step gather, max-over-ranks timing, one line from rank 0),
+    launched exactly as the driver launches it; both ranks share GPU 0 and the exchange goes through gloo, because a one-GPU
+    box cannot host two RCCL ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "10",
+           "--envs-per-gpu", "512", "--rehearse-shared-gpu", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                # rank 0 only
+    d = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(d)
+    assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["state_finite"] is True
+    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate

@@ -54,7 +54,7 @@ MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}
 @pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
 @pytest.mark.parametrize("case", ["A", "B"])
 def test_step_matches_golden_vectors(gold, case, mapping):
-    """Both work mappings of the step kernel (one env per lane / one leg per lane) against the fixture."""
+    """Every work mapping of the step kernel (one env per lane / one leg per lane / two legs per lane) against the fixture."""
     from quadruped_gym_amd.sim import BatchedSim
     task = configure(_abi.default_task(), case)
     n = len(gold["qpos"])
