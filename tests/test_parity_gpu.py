@@ -413,3 +413,34 @@ def test_sharding_does_not_change_results(mapping):
     assert np.array_equal(sw[0], np.concatenate([sp[0][0], sp[1][0]]))
     for s in [whole] + parts:
         s.close()
+
+
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+def test_non_finite_actions_stay_contained(mapping):
+    """NaN / Inf in one env's action must not leak: the other envs step bit-identically to a clean run, +-Inf acts like the
+    clip bound (quadruped.py:160), and the state of every env stays finite (a NaN command either clips or trips the
+    divergence guard, which reports done and resets the env)."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n = 64
+    task = _abi.default_task()
+    task.auto_reset = 1
+    rng = np.random.default_rng(8)
+    clean, dirty = BatchedSim(n, task=task), BatchedSim(n, task=task)
+    for s in (clean, dirty):
+        s.set_mapping(MAPPINGS[mapping])
+    bad = np.array([5, 17, 40])
+    for k in range(6):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        b = a.copy()
+        b[5, 3] = np.nan
+        b[17, :] = np.inf
+        b[40, 7] = -np.inf
+        a[17, :] = 1.0                                    # what the clip makes of +Inf
+        a[40, 7] = -1.0
+        oc, od = clean.step(a), dirty.step(b)
+        keep = np.setdiff1d(np.arange(n), [5])
+        assert np.array_equal(oc[0][keep], od[0][keep]) and np.array_equal(oc[1][keep], od[1][keep])
+        qd, vd = dirty.get_state()[:2]
+        assert np.isfinite(qd).all() and np.isfinite(vd).all()
+    for s in (clean, dirty):
+        s.close()
