@@ -11,7 +11,10 @@ in one kernel launch, inputs (actions) and state already resident in HBM.
 
 N > 1: one process per GPU, env batches sharded (4096 per GPU, weak scaling), no exchange inside the
 physics; per env-step ONE RCCL gather of the packed [envs, obs+2] f32 buffer (obs, reward, done) to
-rank 0 over xGMI, issued on a communication stream and overlapped with the next env-step.
+rank 0 over xGMI, issued on a communication stream and overlapped with the next env-step.  The K timed
+steps are measured with the host issuing kernel + collective per step (eager); then, unless --exchange eager,
+the same K steps are measured again as replays of a hipGraph of 8 env-steps under a watchdog, and the faster
+of the two is reported (`config.exchange` says which; a failed or stalled attempt leaves the eager result).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the step kernel against HBM (algorithmic bytes per
 env-step x envs / average kernel duration measured with HIP events on the kernel's stream);
@@ -129,6 +132,12 @@ def main():
                     help="capture G env-steps (kernel + per-step collective, double-buffered) into one hipGraph and replay it; "
                          "steps and warmup are rounded up to multiples of G.  Validated with a 1-rank RCCL group only: opt-in")
     ap.add_argument("--mapping", choices=["auto", "lane", "quad", "pair"], default="auto", help="work mapping of the step kernel")
+    ap.add_argument("--exchange", choices=["auto", "eager"], default="auto",
+                    help="multi-GPU only.  eager: kernel launch + asynchronous RCCL gather issued per step from the host (~36 us of host "
+                         "work per step).  auto (default): time the eager loop first, then ALSO try the same K steps as replays of a "
+                         "hipGraph of 8 env-steps (kernel + collective, no per-step host work) under a watchdog, and report the faster "
+                         "of the two; if capture or replay fails or stalls, the eager result is what is printed")
+    ap.add_argument("--graph-timeout", type=float, default=90.0, help="seconds the hipGraph attempt of --exchange auto may take")
     args = ap.parse_args()
 
     import torch
@@ -242,13 +251,10 @@ def main():
                 elif len(gatherer.pending) > 64:
                     del gatherer.pending[:-2]
 
-    graph = None
-    if args.graph > 0:
-        if walk is not None or args.rehearse_shared_gpu:
-            raise SystemExit("--graph serves the plain step (with or without the RCCL exchange)")
-        G = args.graph + (args.graph & 1)                # whole double-buffer cycles
-        args.steps = -(-args.steps // G) * G
-        args.warmup = -(-max(args.warmup, G) // G) * G
+    state = {"graph": None, "side": None, "G": 0}
+
+    def build_graph(G):
+        """G env-steps (kernel + asynchronous collective, double-buffered, joined at the end) captured into one hipGraph."""
         side = torch.cuda.Stream(dev)
         side.wait_stream(compute)
         with torch.cuda.stream(side):                    # warm-up on the capture stream (lazy RCCL initialisation happens here)
@@ -278,15 +284,24 @@ def main():
                         gatherer.work[bb].wait()
                         gatherer.work[bb] = None
                 gatherer.pending.clear()
+        state["graph"], state["side"], state["G"] = graph, side, G
+
+    if args.graph > 0:
+        if walk is not None or args.rehearse_shared_gpu:
+            raise SystemExit("--graph serves the plain step (with or without the RCCL exchange)")
+        G = args.graph + (args.graph & 1)                # whole double-buffer cycles
+        args.steps = -(-args.steps // G) * G
+        args.warmup = -(-max(args.warmup, G) // G) * G
+        build_graph(G)
 
     def run(k0, count):
         if native is not None:
             check(lib.qg_comm_rollout(native, a_arr, len(pool), p_arr, g_arr, count, 0), "qg_comm_rollout")
             return
-        if graph is None:
+        if state["graph"] is None:
             return run_eager(k0, count)
-        for _ in range(count // G):
-            graph.replay()
+        for _ in range(count // state["G"]):
+            state["graph"].replay()
 
     def fence():
         if native is not None:
@@ -298,25 +313,36 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    def timed(count):
+        """EXACTLY `count` steps between two fences; returns (seconds, max over ranks; event-span ms per step on the kernel's stream)."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tstream = compute if state["graph"] is None else state["side"]
+        if state["graph"] is not None:
+            torch.cuda.set_stream(state["side"])
+        t0 = time.perf_counter()
+        ev0.record(tstream)
+        run(args.warmup, count)
+        ev1.record(tstream)
+        fence()
+        dt = time.perf_counter() - t0
+        span_ms = ev0.elapsed_time(ev1) / count
+        if use_dist:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, span_ms
+
     run(0, args.warmup)
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    tstream = compute if graph is None else side
-    if graph is not None:
-        torch.cuda.set_stream(side)
-    ev0.record(tstream)
-    run(args.warmup, args.steps)
-    ev1.record(tstream)
-    fence()
-    dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps       # HIP events on the stream the kernel runs on
+    dt, kernel_ms = timed(args.steps)                    # HIP events on the stream the kernel runs on
     if native is not None:
         kernel_ms = dt / args.steps * 1e3                # the C loop runs on the library's own streams: wall clock per step
-    if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    exchange_mode = None
+    if use_dist and native is None:
+        exchange_mode = "hipGraph replay" if state["graph"] is not None else "eager"
+        if walk is None:
+            # with a collective per step the event span is the host's issue period, not the kernel: time the kernel by itself
+            kernel_ms = sim.time_step_kernel(pool[0], packed[0], 200)
 
     qpos = sim.get_state()[0]
     healthy = bool(np.isfinite(qpos).all())
@@ -324,7 +350,7 @@ def main():
     MAP_KEY = {_abi.MAP_LANE: "lane", _abi.MAP_QUAD: "quad", _abi.MAP_PAIR: "pair"}
     MAP_KERNEL = {_abi.MAP_LANE: "qg_step_kernel", _abi.MAP_QUAD: "qg_step_kernel_quad", _abi.MAP_PAIR: "qg_step_kernel_pair"}
     MAP_ENVS_PER_WAVE = {_abi.MAP_LANE: 64, _abi.MAP_QUAD: 16, _abi.MAP_PAIR: 32}
-    if rank == 0:
+    def make_line(dt, kernel_ms, exchange_mode):
         # HBM traffic per launch: committed rocprofv3 PMC measurement of this same configuration, when there is one
         traffic, valu = None, None
         try:
@@ -371,6 +397,56 @@ def main():
             rate = valu * waves / (kernel_ms * 1e-3)
             line["roofline"]["valu_issue"] = {"insts_per_wave": valu, "waves": waves, "achieved_ginst_s": rate / 1e9,
                                               "peak_ginst_s": 1024 * 2.4 / 2, "frac": rate / (1024 * 1.2e9)}
+        if exchange_mode is not None:
+            line["config"]["exchange"] = exchange_mode
+        return line
+
+    line = make_line(dt, kernel_ms, exchange_mode)
+
+    # ---- multi-GPU, --exchange auto: the same K steps again as hipGraph replays, guarded by a watchdog -------------------------
+    # The eager loop is bound by the host's cost of issuing one collective per step (~36 us against an 18 us kernel); a graph of
+    # 8 env-steps has no per-step host work.  Graph replay of RCCL collectives across ranks cannot be validated on a one-GPU box,
+    # so the eager measurement above is ALWAYS taken first and is what gets printed if the attempt raises, stalls or is slower.
+    try_graph = (use_dist and native is None and walk is None and state["graph"] is None and args.exchange == "auto"
+                 and not args.rehearse_shared_gpu and not args.sync_gather and args.gather_op == "gather")
+    fault = os.environ.get("QG_BENCH_GRAPH_FAULT")     # test hook: "raise" / "stall" exercise the two fallbacks of the attempt
+    G = 8 if args.steps % 8 == 0 else (4 if args.steps % 4 == 0 else (2 if args.steps % 2 == 0 else 0))
+    if try_graph and G:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["config"]["exchange_note"] = (f"hipGraph replay of the per-step exchange did not complete within "
+                                                   f"{args.graph_timeout:.0f} s on this node: eager result reported")
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.graph_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        ok, note = 1, None
+        try:
+            if fault == "raise":
+                raise RuntimeError("injected capture failure (QG_BENCH_GRAPH_FAULT=raise)")
+            if fault == "stall":
+                time.sleep(3600)
+            build_graph(G)
+            run(0, G)                                    # one replay as warm-up
+            fence()
+            dt_g, _ = timed(args.steps)
+        except Exception as e:                           # capture or replay refused: stay with the eager result
+            ok, note = 0, f"{type(e).__name__}: {e}"[:300]
+            state["graph"] = None
+        agree = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize(dev)
+        watchdog.cancel()
+        if int(agree.item()) == 1 and dt_g < dt:
+            line = make_line(dt_g, kernel_ms, f"hipGraph replay of {G} env-steps (kernel + collective per step, no per-step host work); "
+                                              f"eager loop measured first: {dt / args.steps * 1e6:.1f} us per step")
+        else:
+            line["config"]["exchange_note"] = (note or ("hipGraph attempt failed on another rank" if int(agree.item()) == 0 else
+                                                        f"hipGraph replay measured slower ({dt_g / args.steps * 1e6:.1f} us per step)"))
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -81,3 +81,29 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert CONTRACT_KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["state_finite"] is True
     assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", [None, "raise", "stall"])
+def test_exchange_auto_reports_a_valid_line_whatever_the_graph_attempt_does(fault):
+    """--exchange auto (the multi-GPU default) measures the eager loop first and then tries hipGraph replays under a watchdog.
+    With a 1-rank RCCL group (--force-gather) on this box: the attempt succeeds; an injected exception falls back to the eager
+    line; an injected stall makes the watchdog print the eager line and end the process with exit code 0."""
+    env = dict(os.environ)
+    if fault:
+        env["QG_BENCH_GRAPH_FAULT"] = fault
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(_free_port())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-gather", "--steps", "400", "--warmup", "40",
+                          "--no-cpu-baseline", "--graph-timeout", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(d) and d["steps"] == 400 and d["n_gpus"] == 1
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    if fault is None:
+        assert d["config"]["exchange"].startswith("hipGraph replay of 8 env-steps") and d["ms_per_step"] < 0.03
+    else:
+        assert d["config"]["exchange"] == "eager" and "exchange_note" in d["config"]
+        assert ("injected" in d["config"]["exchange_note"]) == (fault == "raise")
