@@ -352,3 +352,41 @@ def test_random_yaw_reset(oracle, model, task):
     e = oracle.reset(model, task, seed=123, env_index=5, counter=2, flags=1)
     a = 2 * np.pi * oracle.uniform(123, 5, 2)
     assert np.allclose(np.array(e.qpos[3:7]), [np.cos(a / 2), 0, 0, np.sin(a / 2)])   # walking_quad.py:73-75
+
+
+def test_envelope_of_the_reference_notebook_run(oracle, model, task):
+    """The one recorded output of the real engine in the reference: the joint-angle plot stored in `src/quadruped_model.ipynb`
+    (cell 3) of a 10 s run from reset in which `data.ctrl` is redrawn from U(-1, 1) every 0.1 s (cell 2; NumPy's global RNG,
+    unseeded, so only statistics are comparable).  Digitised from that plot (axes calibrated on its gridlines, 6.8 mrad and
+    11.8 ms per pixel; the eight uniquely coloured curves, 65-80 % of each visible): the joint sensors start at
+    (-0.785, 0.65, 0); hips stay within [-0.784, +0.805] (their +-45 deg range is also the servo's reach 0.5 / 0.64); knees peak
+    at 1.43 (= 0.91 / 0.64, the ctrlrange clamp, reached without overshoot) and dip to -0.84 (55 mrad through the -45 deg limit);
+    ankles swing to +1.46 / -1.40 of their +-1.5625 reach; the fastest sustained motion over 0.1 s is 5.4-5.8 rad/s (hips),
+    6.5 (knees), 5.9-6.3 (ankles) -- the torque-limited slew of the servo (0.64 * 1.71 N m against 0.2 N m s/rad of joint damping
+    and the load).  The same protocol through the oracle must give the same envelope and slew rates; this is a loose pin
+    (one unseeded run, read off a picture), not bit-level parity."""
+    lo = np.array([+9.0] * 3)
+    hi = np.array([-9.0] * 3)
+    rate = np.zeros(3)
+    for seed in range(3):
+        rng = np.random.default_rng(seed)
+        e = oracle.reset(model, task)
+        ctrl = np.array([0.0, 0.0, -0.5] * 4)
+        count, time = 0, 0.0
+        traj = np.empty((5000, 12))
+        for s in range(5000):
+            sens = oracle.substep(model, e, ctrl, want_sensors=True)
+            traj[s] = np.array(sens[0][:12] if isinstance(sens, tuple) else sens[:12])
+            time += 0.002
+            if count < time * 10:                      # notebook cell 2: a new random command whenever count < time * 10
+                ctrl = rng.uniform(-1, 1, 12)
+                count += 1
+        assert np.allclose(traj[0].reshape(4, 3), [[-0.7854, 0.6545, 0.0]] * 4, atol=2e-3)
+        for j in range(3):
+            q = traj[:, j::3]
+            lo[j], hi[j] = min(lo[j], q.min()), max(hi[j], q.max())
+            rate[j] = max(rate[j], (np.abs(q[50:] - q[:-50]) / 0.1).max())
+    assert -0.83 < lo[0] < -0.76 and 0.76 < hi[0] < 0.83           # hips: plateaus at the +-45 deg limit
+    assert 1.25 < hi[1] < 1.47 and -0.90 < lo[1] < -0.75           # knees: 1.42 reach, shallow dip through the lower limit
+    assert 1.25 < hi[2] < 1.60 and -1.60 < lo[2] < -1.25           # ankles: most of the +-1.5625 reach, inside the +-90 deg range
+    assert (rate > 5.0).all() and (rate < 7.8).all()               # torque-limited slew: 5.4-6.5 rad/s in the plot's visible parts
