@@ -21,7 +21,10 @@
  * recursive Newton-Euler bias, linearly-implicit velocity integration), and it
  * is pinned by the known-answer tests in tests/test_oracle_physics.py (energy
  * and momentum conservation, M*a + c == RNE(q, v, a), servo filter closed form,
- * 4-fold symmetry, exact discrete free fall).  Constraints (ground contact and
+ * 4-fold symmetry, exact discrete free fall) and, loosely, by the one recorded
+ * output of the real engine the reference holds: the joint-angle plot stored in
+ * src/quadruped_model.ipynb, whose envelope and slew rates the same protocol run
+ * through this file reproduces (tools/digitize_notebook_plot.py).  Constraints (ground contact and
  * joint limits) are this project's own LCP-free penalty model, not
  * a restatement of the engine's convex solver (Appendix A.5, A.9).
  *
