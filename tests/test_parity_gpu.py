@@ -444,3 +444,34 @@ def test_non_finite_actions_stay_contained(mapping):
         assert np.isfinite(qd).all() and np.isfinite(vd).all()
     for s in (clean, dirty):
         s.close()
+
+
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("n", [1, 15, 33])
+def test_tiny_and_ragged_batches(oracle, mapping, n):
+    """A single env, less than one quad-wave's 16 envs, and one env past the pair-wave's 32: the tail lanes shadow the last
+    env and must neither write nor disturb it."""
+    from quadruped_gym_amd.sim import BatchedSim
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_golden import sample_states
+    model, task = oracle.default_model(), configure(oracle.default_task(), "A")
+    qpos, qvel, act, nstep = sample_states(model, task, n, seed=300 + n)
+    actions = np.random.default_rng(n).uniform(-1, 1, (n, 12)).astype(np.float32)
+    b = oracle.Batch(model, task, n)
+    b.set_state(qpos.astype(np.float64), qvel.astype(np.float64), act.astype(np.float64), None, nstep)
+    obs_o, rew_o, done_o, _ = b.step(actions.astype(np.float64))
+    q_o, v_o = b.get_state()[:2]
+    sim = BatchedSim(n, task=configure(_abi.default_task(), "A"))
+    sim.set_mapping(MAPPINGS[mapping])
+    sim.set_state(qpos, qvel, act, None, nstep)
+    obs, rew, done, _ = sim.step(actions)
+    q1, v1 = sim.get_state()[:2]
+    t = TOL["A"]
+    mask = np.ones(33, bool)
+    mask[12:15] = False
+    close(obs[:, mask], obs_o[:, mask], t["obs"], "obs")
+    close(rew, rew_o, t["reward"], "reward")
+    close(q1, q_o, t["qpos"], "qpos")
+    close(v1, v_o, t["qvel"], "qvel")
+    sim.close()
