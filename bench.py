@@ -67,7 +67,7 @@ def cpu_baseline(n_envs: int, frame_skip: int, seconds: float):
     dt = time.perf_counter() - t0
     out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{n} envs x {steps} env-steps (frame_skip {frame_skip}) of the same workload, single thread, {dt:.1f} s",
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
     # all host cores: independent shards in threads (ctypes releases the GIL inside the C call)
     try:
         import threading
@@ -102,6 +102,17 @@ def cpu_baseline(n_envs: int, frame_skip: int, seconds: float):
     except Exception:
         out["mujoco"] = "unavailable on this host (reference engine not installed; B0 row of BASELINE.md not measurable)"
     return out
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
