@@ -230,7 +230,8 @@ typedef struct qg_walk_params {
 typedef struct qg_walk qg_walk;
 
 int qg_walk_default_params(qg_walk_params *out);
-/* Binds the task layer to `sim` (switches its flip termination and data.ctrl tracking on). */
+/* Binds the task layer to `sim` (switches its flip termination and data.ctrl tracking on).  Lifetime: a qg_walk borrows its
+ * qg_sim and a qg_po borrows its qg_walk -- destroy them in the order po, walk, sim. */
 int qg_walk_create(qg_sim *sim, const qg_walk_params *params, qg_walk **out);
 int qg_walk_destroy(qg_walk *walk);
 /* control_inputs.py: per-env local velocity (vx, vy) and heading unit vector (cos, sin); host pointers [n][2]. */
