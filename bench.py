@@ -451,7 +451,10 @@ def main():
         dist.all_reduce(agree, op=dist.ReduceOp.MIN)
         torch.cuda.synchronize(dev)
         watchdog.cancel()
-        if int(agree.item()) == 1 and dt_g < dt:
+        plausible = ok == 1 and dt_g / args.steps * 1e3 >= 0.9 * kernel_ms     # a step cannot take less than its own kernel
+        if int(agree.item()) == 1 and not plausible:
+            note = f"hipGraph replay timed an implausible {dt_g / args.steps * 1e6:.1f} us per step (kernel alone: {kernel_ms * 1e3:.1f} us): discarded"
+        if int(agree.item()) == 1 and plausible and dt_g < dt:
             line = make_line(dt_g, kernel_ms, f"hipGraph replay of {G} env-steps (kernel + collective per step, no per-step host work); "
                                               f"eager loop measured first: {dt / args.steps * 1e6:.1f} us per step")
         else:
