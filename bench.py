@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STALL_EXIT = 3                 # exit status when the hipGraph attempt of --exchange auto hangs the GPU (the eager line is still printed)
 FP32_PEAK_TFLOPS = 157.3       # vector FP32 spec peak
 
 
@@ -71,7 +72,7 @@ def cpu_baseline(n_envs: int, frame_skip: int, seconds: float):
     # all host cores: independent shards in threads (ctypes releases the GIL inside the C call)
     try:
         import threading
-        nthr = max(1, min(os.cpu_count() or 1, 16))
+        nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))   # every core this process may use
         batches = []
         for i in range(nthr):
             b = O.Batch(model, task, n)
@@ -149,6 +150,9 @@ def main():
                          "hipGraph of 8 env-steps (kernel + collective, no per-step host work) under a watchdog, and report the faster "
                          "of the two; if capture or replay fails or stalls, the eager result is what is printed")
     ap.add_argument("--graph-timeout", type=float, default=90.0, help="seconds the hipGraph attempt of --exchange auto may take")
+    ap.add_argument("--no-track-ctrl", action="store_true",
+                    help="development only: skip the data.ctrl write-back (48 B/env) the reference's step maintains; such a line is "
+                         "marked `ctrl_tracking: false` and is not the reported configuration")
     args = ap.parse_args()
 
     import torch
@@ -193,7 +197,8 @@ def main():
         model = _abi.default_model()
         model.body_mass[3] *= 1.001
     sim = BatchedSim(n, device=local_rank, model=model, task=task, env_index_base=rank * n)
-    sim.set_track_ctrl(False)
+    # data.ctrl is written back every step, as the reference's step maintains it (quadruped.py:164): the timed region skips nothing
+    sim.set_track_ctrl(not args.no_track_ctrl)
     sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}[args.mapping])
     mapping_name = {_abi.MAP_LANE: "one env per lane", _abi.MAP_QUAD: "one leg per lane (4 lanes per env)",
                     _abi.MAP_PAIR: "two legs per lane, packed f32 (2 lanes per env)"}[sim.mapping]
@@ -363,14 +368,19 @@ def main():
     MAP_ENVS_PER_WAVE = {_abi.MAP_LANE: 64, _abi.MAP_QUAD: 16, _abi.MAP_PAIR: 32}
     def make_line(dt, kernel_ms, exchange_mode):
         # HBM traffic per launch: committed rocprofv3 PMC measurement of this same configuration, when there is one
-        traffic, valu = None, None
+        traffic, valu, flops = None, None, None
         try:
             key = f"{MAP_KEY[sim.mapping]}_n{n}_fs{args.frame_skip}_obs{od}"
             with open(os.path.join(ROOT, "profiles", "traffic_index.json")) as fh:
-                ent = json.load(fh).get(key)
+                idx = json.load(fh)
+            ent = idx.get(key)
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]
                 valu = ent.get("valu_insts_per_wave")
+            # counted FP32 flops per env-step (SQ_INSTS_VALU_FLOPS_FP32 of the step kernel / envs; FMA = 2): a property of the
+            # kernel's instruction stream per substep, so the entry of the same mapping and frame_skip serves every batch size
+            fkey = f"flops_{MAP_KEY[sim.mapping]}_fs{args.frame_skip}"
+            flops = idx.get(fkey)
         except Exception:
             pass
         total_envs = n * world
@@ -408,6 +418,14 @@ def main():
             rate = valu * waves / (kernel_ms * 1e-3)
             line["roofline"]["valu_issue"] = {"insts_per_wave": valu, "waves": waves, "achieved_ginst_s": rate / 1e9,
                                               "peak_ginst_s": 1024 * 2.4 / 2, "frac": rate / (1024 * 1.2e9)}
+        if flops:
+            # the FP32 vector-ALU view -- counted flops per env-step x env-steps/s of the kernel against the 157.3 TFLOP/s
+            # vector peak (which assumes every issue slot holds an FMA: a stream of dependent small solves cannot reach it)
+            per = flops["flops_per_env_step"]
+            tf = per * n / (kernel_ms * 1e-3) / 1e12
+            line["roofline"]["fp32"] = {"flops_per_env_step": per, "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": tf / FP32_PEAK_TFLOPS, "flop_per_byte": per / bytes_step, "source": flops.get("source")}
+        line["config"]["ctrl_tracking"] = not args.no_track_ctrl
         if exchange_mode is not None:
             line["config"]["exchange"] = exchange_mode
         return line
@@ -426,39 +444,58 @@ def main():
         import threading
 
         def give_up():
+            # GPU work (a collective inside the replayed graph) did not finish: the eager measurement taken before it is still
+            # valid and is printed, marked, but a stalled GPU is NOT a success -- the process ends with a non-zero status
             if rank == 0:
+                line["graph_stalled"] = True
                 line["config"]["exchange_note"] = (f"hipGraph replay of the per-step exchange did not complete within "
-                                                   f"{args.graph_timeout:.0f} s on this node: eager result reported")
+                                                   f"{args.graph_timeout:.0f} s on this node: eager result reported, exit status {STALL_EXIT}")
                 print(json.dumps(line), flush=True)
-            os._exit(0)
+            os._exit(STALL_EXIT)
         watchdog = threading.Timer(args.graph_timeout, give_up)
         watchdog.daemon = True
         watchdog.start()
-        ok, note = 1, None
-        try:
+
+        def all_ok(flag):
+            t = torch.tensor([flag], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            torch.cuda.synchronize(dev)
+            return int(t.item()) == 1
+        ok, note, dt_g = 1, None, float("inf")
+        try:                                             # phase 1: capture (no replay yet)
             if fault == "raise":
                 raise RuntimeError("injected capture failure (QG_BENCH_GRAPH_FAULT=raise)")
             if fault == "stall":
                 time.sleep(3600)
             build_graph(G)
-            run(0, G)                                    # one replay as warm-up
-            fence()
-            dt_g, _ = timed(args.steps)
-        except Exception as e:                           # capture or replay refused: stay with the eager result
+        except Exception as e:                           # capture refused on this rank
             ok, note = 0, f"{type(e).__name__}: {e}"[:300]
+        # every rank learns whether EVERY rank holds a graph before any of them replays one: a rank that failed to capture
+        # would otherwise sit in this all_reduce while its peers issue the captured gathers (mismatched collectives)
+        captured = all_ok(ok)
+        if not captured:
             state["graph"] = None
-        agree = torch.tensor([ok], device=dev, dtype=torch.int32)
-        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-        torch.cuda.synchronize(dev)
+            torch.cuda.set_stream(compute)
+        else:
+            try:                                         # phase 2: replay
+                run(0, G)                                # one replay as warm-up
+                fence()
+                dt_g, _ = timed(args.steps)
+            except Exception as e:
+                ok, note = 0, f"{type(e).__name__}: {e}"[:300]
+                state["graph"] = None
+                torch.cuda.set_stream(compute)
+        agreed = all_ok(ok) if captured else False
         watchdog.cancel()
         plausible = ok == 1 and dt_g / args.steps * 1e3 >= 0.9 * kernel_ms     # a step cannot take less than its own kernel
-        if int(agree.item()) == 1 and not plausible:
+        if agreed and not plausible:
             note = f"hipGraph replay timed an implausible {dt_g / args.steps * 1e6:.1f} us per step (kernel alone: {kernel_ms * 1e3:.1f} us): discarded"
-        if int(agree.item()) == 1 and plausible and dt_g < dt:
+        if agreed and plausible and dt_g < dt:
             line = make_line(dt_g, kernel_ms, f"hipGraph replay of {G} env-steps (kernel + collective per step, no per-step host work); "
                                               f"eager loop measured first: {dt / args.steps * 1e6:.1f} us per step")
         else:
-            line["config"]["exchange_note"] = (note or ("hipGraph attempt failed on another rank" if int(agree.item()) == 0 else
+            line["graph_stalled"] = False
+            line["config"]["exchange_note"] = (note or ("hipGraph attempt failed on another rank" if not agreed else
                                                         f"hipGraph replay measured slower ({dt_g / args.steps * 1e6:.1f} us per step)"))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -14,6 +14,16 @@
  * backend: every compute entry point fails with QG_ERR_DEVICE when no HIP device
  * is usable.
  *
+ * Ordering contract.  The *_device entry points (qg_step_device, qg_step_device_packed,
+ * qg_walk_step_device, qg_po_step_device) enqueue on the caller's stream and return at once;
+ * consecutive calls on ONE stream are ordered by that stream, calls on different streams are the
+ * caller's to order.  Every other entry point that touches the per-env state (qg_reset,
+ * qg_walk_reset, qg_po_reset, the host-pointer qg_step / qg_walk_step / qg_po_step,
+ * qg_get_state / qg_set_state, the command and estimate accessors, the destroy calls) first waits
+ * for ALL work on the handle's device (hipDeviceSynchronize), runs on the library's own stream and
+ * returns when it has completed -- it can therefore follow device-pointer steps on any stream
+ * without further synchronisation, and must not be called while a stream is being captured.
+ *
  * Layouts at the boundary (row-major, env-major -- what NumPy / torch hand over):
  *   actions  [n_envs][12] f32      obs   [n_envs][obs_dim] f32
  *   reward   [n_envs] f32          done  [n_envs] u8
@@ -148,7 +158,10 @@ int qg_obs_dim(const qg_sim *sim);
 /* Replaces QuadrupedEnv.reset (quadruped.py:115-139): mj_resetData, time = 0,
  * ctrl = default.  mask == NULL resets every env, else only mask[i] != 0
  * (host pointer, n_envs bytes).  The first observation is all zeros, as in the
- * reference (no mj_forward after mj_resetData). */
+ * reference (no mj_forward after mj_resetData).  `seed` keys the reset random
+ * streams (yaw, hinge jitter, commands) of every env of the batch, auto-resets
+ * included: it is adopted by a whole-batch reset only (mask == NULL); a masked
+ * reset ignores it and draws from the streams already in force. */
 int qg_reset(qg_sim *sim, const uint8_t *mask, uint64_t seed, uint32_t flags);
 
 /* Replaces QuadrupedEnv.step (quadruped.py:153-182) for the whole batch: clip to
@@ -173,6 +186,13 @@ int qg_set_state(qg_sim *sim, const float *qpos, const float *qvel, const float 
  * stream bracketed by HIP events on that stream; returns the mean milliseconds
  * per launch in *ms_per_launch.  State advances `iters` env-steps. */
 int qg_time_step_kernel(qg_sim *sim, const float *d_actions, float *d_packed, int32_t iters, float *ms_per_launch);
+
+/* Replace the task constants of a live handle -- what assigning env.reward_fns / env.termination_fns / env.max_time after
+ * construction does in the reference (README.md:74-89): reward weights, fall / flip / time-limit terminations, auto-reset
+ * and its flags, frame_skip.  obs_mode is fixed at qg_create.  Refused while a walking task layer is bound.  Takes effect
+ * from the next step; waits for steps in flight. */
+int qg_set_task(qg_sim *sim, const qg_task *task);
+int qg_get_task(const qg_sim *sim, qg_task *out);
 
 /* data.ctrl (the last env-clipped action, quadruped.py:164) is written back each step only
  * while this is on (default on; bulk-throughput callers switch it off). */
@@ -230,8 +250,9 @@ typedef struct qg_walk_params {
 typedef struct qg_walk qg_walk;
 
 int qg_walk_default_params(qg_walk_params *out);
-/* Binds the task layer to `sim` (switches its flip termination and data.ctrl tracking on).  Lifetime: a qg_walk borrows its
- * qg_sim and a qg_po borrows its qg_walk -- destroy them in the order po, walk, sim. */
+/* Binds the task layer to `sim` (switches its flip termination and data.ctrl tracking on; qg_walk_destroy switches both back
+ * to what they were).  Lifetime: a qg_walk borrows its qg_sim and a qg_po borrows its qg_walk -- destroy them in the order
+ * po, walk, sim. */
 int qg_walk_create(qg_sim *sim, const qg_walk_params *params, qg_walk **out);
 int qg_walk_destroy(qg_walk *walk);
 /* control_inputs.py: per-env local velocity (vx, vy) and heading unit vector (cos, sin); host pointers [n][2]. */

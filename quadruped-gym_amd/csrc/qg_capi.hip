@@ -41,6 +41,7 @@ struct qg_sim {
     int32_t baked;            // 1: the model equals the compiled-in default, the literal-constant kernel variant runs
     int32_t mapping;          // QG_MAP_AUTO / QG_MAP_LANE / QG_MAP_QUAD (request)
     int32_t creating;
+    int32_t walk_bound;       // qg_walk layers bound to this handle (qg_set_task refuses while > 0)
 };
 
 static thread_local char g_err[512] = "";
@@ -196,7 +197,13 @@ extern "C" int qg_obs_dim(const qg_sim *s) { return s ? s->obs_dim : fail(QG_ERR
 extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t flags) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
-    s->seed = seed;
+    // steps may be in flight on a caller's stream (qg_step_device*): the reset runs on the library's own non-blocking stream
+    // and must not overlap them
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    // the seed keys the reset streams of EVERY env (auto-resets included): only a whole-batch reset may change it, a masked
+    // reset draws from the streams already in force
+    if (!mask) s->seed = seed;
+    else seed = s->seed;
     const uint8_t *dmask = nullptr;
     if (mask) {
         HIP_TRY(hipMemcpyAsync(s->d_mask, mask, (size_t)s->n, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
@@ -287,6 +294,7 @@ extern "C" int qg_step_device_packed(qg_sim *s, const float *actions, float *pac
 extern "C" int qg_step(qg_sim *s, const float *actions, float *obs, float *reward, uint8_t *done, float *comps) {
     if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step: null argument");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     size_t n = (size_t)s->n;
     HIP_TRY(hipMemcpyAsync(s->d_actions, actions, n * QG_NU * sizeof(float), hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
     int rc = launch_step(s, s->d_actions, s->d_obs, s->d_reward, s->d_done, comps ? s->d_comps : nullptr, nullptr, s->stream);
@@ -349,23 +357,20 @@ extern "C" int qg_time_step_kernel(qg_sim *s, const float *d_actions, float *d_p
     if (!s || !d_actions || !d_packed || iters < 1 || !ms_per_launch) return fail(QG_ERR_ARG, "qg_time_step_kernel: bad argument");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
-    int keep = s->track_ctrl;
-    s->track_ctrl = 0;
+    // the launches are exactly what qg_step_device_packed enqueues (data.ctrl write-back as the handle has it set)
     HIP_TRY(hipEventRecord(s->ev0, s->stream), QG_ERR_DEVICE);
     for (int i = 0; i < iters; i++) {
         int rc = launch_step(s, d_actions, nullptr, nullptr, nullptr, nullptr, d_packed, s->stream);
-        if (rc != QG_OK) { s->track_ctrl = keep; return rc; }
+        if (rc != QG_OK) return rc;
     }
     HIP_TRY(hipEventRecord(s->ev1, s->stream), QG_ERR_DEVICE);
     HIP_TRY(hipEventSynchronize(s->ev1), QG_ERR_LAUNCH);
-    s->track_ctrl = keep;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1), QG_ERR_DEVICE);
     *ms_per_launch = ms / (float)iters;
     return QG_OK;
 }
 
-/* selects whether data.ctrl is written back each step (needed by QuadrupedEnv's `data.ctrl` view; off for raw throughput) */
 extern "C" int qg_set_mapping(qg_sim *s, int32_t mapping) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     if (mapping == QG_MAP_PAIR && !s->baked)
@@ -378,6 +383,27 @@ extern "C" int qg_get_mapping(const qg_sim *s) { return s ? effective_mapping(s)
 
 /* 1 if the handle runs the kernel variant with the default robot's constants baked in as literals */
 extern "C" int qg_uses_baked_model(const qg_sim *s) { return s ? s->baked : fail(QG_ERR_ARG, "null handle"); }
+
+extern "C" int qg_set_task(qg_sim *s, const qg_task *task) {
+    if (!s || !task) return fail(QG_ERR_ARG, "qg_set_task: null argument");
+    if (s->walk_bound) return fail(QG_ERR_ARG, "qg_set_task: a walking task layer is bound to this handle (it holds a copy of the task)");
+    if (task->obs_mode != s->task.obs_mode) return fail(QG_ERR_ARG, "qg_set_task: obs_mode is fixed at qg_create (it sizes the output rows)");
+    KModel km;
+    KTask kt;
+    int rc = build_tables(&s->model, task, &km, &kt);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps reading the old task may be in flight on a caller's stream
+    HIP_TRY(hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice), QG_ERR_DEVICE);
+    s->task = *task;
+    return QG_OK;
+}
+
+extern "C" int qg_get_task(const qg_sim *s, qg_task *out) {
+    if (!s || !out) return fail(QG_ERR_ARG, "qg_get_task: null argument");
+    *out = s->task;
+    return QG_OK;
+}
 
 extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
@@ -487,6 +513,7 @@ extern "C" int qg_comm_synchronize(qg_comm *c) {
 // ------------------------------------------------------------------------------------------------------
 struct qg_walk {
     qg_sim *sim;
+    int32_t saved_use_flip, saved_track_ctrl, bound;     // what qg_walk_create changed on the sim; restored by qg_walk_destroy
     qg_walk_params params;
     KWalkParams kp;
     KWalkState st;
@@ -516,6 +543,16 @@ extern "C" int qg_walk_default_params(qg_walk_params *p) {
 extern "C" int qg_walk_destroy(qg_walk *w) {
     if (!w) return QG_OK;
     (void)hipSetDevice(w->sim->device);
+    (void)hipDeviceSynchronize();                  // steps that read the task state may still be in flight on a caller's stream
+    if (w->bound) {                                // give the sim back as qg_walk_create found it
+        qg_sim *s = w->sim;
+        s->task.use_flip = w->saved_use_flip;
+        s->track_ctrl = w->saved_track_ctrl;
+        s->walk_bound -= 1;
+        KModel km;
+        KTask kt;
+        if (build_tables(&s->model, &s->task, &km, &kt) == QG_OK) (void)hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice);
+    }
     void *ptrs[] = {w->st.vel, w->st.head, w->st.gvel, w->st.ideal, w->st.prev_ctrl, w->st.prev_ctrl_cost, w->st.has_ctrl_cost,
                     w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.cross, w->st.count, w->st.prev, w->st.sign,
                     w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done};
@@ -579,6 +616,10 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     WALLOC(w->d_actions, n * 12 * 4); WALLOC(w->d_tmp, n * 12 * 4); WALLOC(w->d_done, n);
 #undef WALLOC
     // the reference's termination set for this env: flip or time limit (walking_quad.py:162-166); data.ctrl feeds the estimator
+    w->saved_use_flip = s->task.use_flip;
+    w->saved_track_ctrl = s->track_ctrl;
+    w->bound = 1;
+    s->walk_bound += 1;
     s->task.use_flip = 1;
     {
         KModel km;
@@ -715,6 +756,7 @@ extern "C" int qg_walk_step(qg_walk *w, const float *actions, float *obs, float 
     if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step: null argument");
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     size_t n = (size_t)s->n;
     HIP_TRY(hipMemcpyAsync(w->d_actions, actions, n * 12 * 4, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
     int rc = qg_walk_step_device(w, w->d_actions, w->d_obs, w->d_reward, w->d_done, components ? w->d_comps : nullptr, s->stream);
@@ -833,6 +875,7 @@ extern "C" int qg_po_reset(qg_po *p, const uint8_t *mask, uint64_t seed, uint32_
     qg_sim *s = p->walk->sim;
     // the reset frame shows the estimate and the command as they stand BEFORE the robots / commands are reset (:59-69)
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     if (mask) HIP_TRY(hipMemcpy(s->d_mask, mask, (size_t)s->n, hipMemcpyHostToDevice), QG_ERR_DEVICE);
     int rc = po_reset_kernel(p, mask ? s->d_mask : nullptr, p->d_out);
     if (rc != QG_OK) return rc;
@@ -860,6 +903,7 @@ extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *rew
     qg_walk *w = p->walk;
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     size_t n = (size_t)s->n, width = (size_t)p->kp.window * QG_PO_FRAME;
     HIP_TRY(hipMemcpyAsync(w->d_actions, actions, n * 12 * 4, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
     int rc = qg_po_step_device(p, w->d_actions, p->d_out, w->d_reward, w->d_done, components ? w->d_comps : nullptr,

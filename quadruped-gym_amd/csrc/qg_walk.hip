@@ -194,9 +194,14 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
         S.has_ctrl_cost[env] = 1;
     }
     const float control_cost = P.control_cost_alpha * first_cost + (1.f - P.control_cost_alpha) * cost;
-    // progress terms on the local (velocimeter) velocity (:197-218); unit() of a zero vector is NaN, as in the reference
+    // progress terms on the local (velocimeter) velocity (:197-218).  unit() of a zero vector is NaN in the reference
+    // (math_utils.py:7-8) and that NaN reaches the direction term and the total.  The device pass is compiled with
+    // -ffinite-math-only, under which 0/0 is formally undefined, so the documented NaN is produced explicitly: the
+    // division is guarded and the quiet-NaN bit pattern is stored through integer selects below.
     const float nv = __builtin_sqrtf(vx * vx + vy * vy), nc = __builtin_sqrtf(cvx * cvx + cvy * cvy);
-    const float direction = (vx / nv) * (cvx / nc) + (vy / nv) * (cvy / nc);
+    const bool degenerate = (nv == 0.f) || (nc == 0.f);
+    const float dv = degenerate ? 1.f : nv, dc = degenerate ? 1.f : nc;
+    const float direction = (vx / dv) * (cvx / dc) + (vy / dv) * (cvy / dc);
     const float dsp = nv - nc;
     const float speed_cost = dsp * dsp;
     const float heading = xax * hx + xay * hy;                       // :231-235
@@ -222,10 +227,12 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
     float total = 0.f;
 #pragma unroll
     for (int k = 0; k < 11; ++k) total += v[k];                       // :422 sum(values), in order
-    reward[env] = total;
+    const unsigned qnan = 0x7FC00000u;
+    reinterpret_cast<unsigned *>(reward)[env] = degenerate ? qnan : __builtin_bit_cast(unsigned, total);
     if (comps) {
+        unsigned *cu = reinterpret_cast<unsigned *>(comps) + (size_t)env * 11;
 #pragma unroll
-        for (int k = 0; k < 11; ++k) comps[(size_t)env * 11 + k] = v[k];
+        for (int k = 0; k < 11; ++k) cu[k] = (k == 2 && degenerate) ? qnan : __builtin_bit_cast(unsigned, v[k]);
     }
     S.calls[env] += 1;                                                // the estimator update of this step is complete
     // episode bookkeeping of envs the physics kernel has just auto-reset (walking_quad.py:96-126)

@@ -51,7 +51,7 @@ class WalkingQuadrupedVecEnv:
 
     def __init__(self, num_envs, settling_time=0, random_controls=False, random_init=False, reset_options=None,
                  model_path="builtin", max_time=10.0, frame_skip=4, device=0, env_index_base=0, seed=0, walk_params=None,
-                 device_commands=False):
+                 device_commands=False, auto_reset=True, use_default_termination=True):
         qg_model, layout = load_model(model_path)
         self.model = ModelView(qg_model, layout)
         self.num_envs = int(num_envs)
@@ -60,10 +60,13 @@ class WalkingQuadrupedVecEnv:
         task = _abi.default_task()
         task.frame_skip = self.frame_skip
         task.max_time = self.max_time
-        task.use_time_limit = 1
+        task.use_time_limit = 1 if use_default_termination else 0   # quadruped.py:52,99-100
         task.use_fall = 0
         task.use_flip = 1                                   # walking_quad.py:156-166
-        task.auto_reset = 1
+        # VecEnv semantics: finished envs restart inside the step.  The single-robot facades switch it off: there the caller
+        # resets, as with the reference's env (a finished robot left alone keeps reporting `terminated`)
+        self.auto_reset = bool(auto_reset)
+        task.auto_reset = 1 if self.auto_reset else 0
         task.reset_flags = _abi.RESET_RANDOM_YAW if random_init else 0     # walking_quad.py:68-75,118-119
         self._sim = BatchedSim(self.num_envs, device=device, model=qg_model, task=task, env_index_base=env_index_base)
         self._lib = _abi.load_library()
@@ -130,14 +133,15 @@ class WalkingQuadrupedVecEnv:
               "qg_walk_step")
         dones = done.astype(bool)
         infos = [dict(zip(REWARD_KEYS, row)) for row in comps.tolist()]
-        for i in np.nonzero(dones)[0]:
-            infos[i]["terminal_observation"] = obs[i].copy()
-            infos[i]["TimeLimit.truncated"] = False
-        if dones.any():
-            obs = obs.copy()
-            obs[dones] = 0.0
-            if self.random_controls:
-                self._resample(np.nonzero(dones)[0])
+        if self.auto_reset:
+            for i in np.nonzero(dones)[0]:
+                infos[i]["terminal_observation"] = obs[i].copy()
+                infos[i]["TimeLimit.truncated"] = False
+            if dones.any():
+                obs = obs.copy()
+                obs[dones] = 0.0
+                if self.random_controls:
+                    self._resample(np.nonzero(dones)[0])
         self.last_components = comps
         return obs, rew, dones, infos
 
@@ -186,6 +190,27 @@ class WalkingQuadrupedVecEnv:
         return [False for _ in idx]
 
 
+def _facade_kwargs(kwargs, allowed):
+    """Keyword arguments the reference forwards to ``QuadrupedEnv.__init__`` (``walking_quad.py:11-12``).  The rendering ones
+    are accepted when they ask for nothing; ``reward_fns`` / ``termination_fns`` would REPLACE the task's reward and
+    terminations in the reference (``quadruped.py:97-100``) -- the device task layer cannot honour that, so it refuses
+    instead of silently running the built-in walking reward."""
+    display = {"render_mode", "width", "height", "render_fps", "save_video", "video_path"}
+    extra = set(kwargs) - allowed - display - {"reward_fns", "termination_fns"}
+    if extra:
+        raise TypeError(f"unexpected keyword arguments {sorted(extra)}")
+    if kwargs.get("render_mode") is not None or kwargs.get("save_video"):
+        raise NotImplementedError("rendering / video recording is not part of the HIP path")
+    for key in ("reward_fns", "termination_fns"):
+        if kwargs.get(key) is not None:
+            raise NotImplementedError(f"{key}: the walking task layer evaluates the reference's input_control_reward and flip / "
+                                      "time-limit terminations on the device; custom callables run through QuadrupedEnv / "
+                                      "QuadrupedVecEnv")
+    args = {k: v for k, v in kwargs.items() if k in allowed}
+    args.setdefault("model_path", "./models/quadruped/scene.xml")      # quadruped.py:41
+    return args
+
+
 class WalkingQuadrupedEnv:
     """One walking robot with the reference's constructor (``walking_quad.py:11``): ``settling_time``,
     ``random_controls``, ``random_init``, ``reset_options`` plus the base env's keyword arguments;
@@ -194,17 +219,8 @@ class WalkingQuadrupedEnv:
     reward_keys = REWARD_KEYS
 
     def __init__(self, settling_time=0, random_controls=False, random_init=False, reset_options=None, **kwargs):
-        allowed = {"model_path", "max_time", "frame_skip", "device"}
-        ignored = {"render_mode", "width", "height", "render_fps", "save_video", "video_path", "use_default_termination",
-                   "reward_fns", "termination_fns"}
-        extra = set(kwargs) - allowed - ignored
-        if extra:
-            raise TypeError(f"unexpected keyword arguments {sorted(extra)}")
-        if kwargs.get("render_mode") is not None or kwargs.get("save_video"):
-            raise NotImplementedError("rendering / video recording is not part of the HIP path")
-        args = {k: v for k, v in kwargs.items() if k in allowed}
-        args.setdefault("model_path", "./models/quadruped/scene.xml")      # quadruped.py:41
-        self._vec = WalkingQuadrupedVecEnv(1, settling_time, random_controls, random_init, reset_options, **args)
+        args = _facade_kwargs(kwargs, {"model_path", "max_time", "frame_skip", "device", "use_default_termination"})
+        self._vec = WalkingQuadrupedVecEnv(1, settling_time, random_controls, random_init, reset_options, auto_reset=False, **args)
         self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
         self.model = self._vec.model
         self.info = {}
@@ -218,12 +234,8 @@ class WalkingQuadrupedEnv:
 
     def step(self, action):
         obs, rew, dones, infos = self._vec.step(np.asarray(action, np.float32)[None])
-        info = dict(infos[0])
-        term_obs = info.pop("terminal_observation", None)
-        info.pop("TimeLimit.truncated", None)
-        self.info = info
-        out = term_obs if term_obs is not None else obs[0]     # a single env is not auto-continued: hand back the last obs
-        return out.astype(np.float64), float(rew[0]), bool(dones[0]), False, self.info
+        self.info = dict(infos[0])                             # walking_quad.py:146-148: info = the component dict
+        return obs[0].astype(np.float64), float(rew[0]), bool(dones[0]), False, self.info
 
     def set_command(self, velocity_xy, heading_xy):
         self._vec.set_commands([velocity_xy], [heading_xy])
@@ -269,11 +281,12 @@ class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
                                    term.ctypes.data), "qg_po_step")
         dones = done.astype(bool)
         infos = [dict(zip(REWARD_KEYS, row)) for row in comps.tolist()]
-        for i in np.nonzero(dones)[0]:
-            infos[i]["terminal_observation"] = term[i].copy()
-            infos[i]["TimeLimit.truncated"] = False
-        if dones.any() and self.random_controls:
-            self._resample(np.nonzero(dones)[0])
+        if self.auto_reset:
+            for i in np.nonzero(dones)[0]:
+                infos[i]["terminal_observation"] = term[i].copy()
+                infos[i]["TimeLimit.truncated"] = False
+            if dones.any() and self.random_controls:
+                self._resample(np.nonzero(dones)[0])
         self.last_components = comps
         return obs, rew, dones, infos
 
@@ -300,17 +313,9 @@ class POWalkingQuadrupedEnv:
     reward_keys = REWARD_KEYS
 
     def __init__(self, obs_window=1, **kwargs):
-        allowed = {"settling_time", "random_controls", "random_init", "reset_options", "model_path", "max_time", "frame_skip", "device"}
-        ignored = {"render_mode", "width", "height", "render_fps", "save_video", "video_path", "use_default_termination",
-                   "reward_fns", "termination_fns"}
-        extra = set(kwargs) - allowed - ignored
-        if extra:
-            raise TypeError(f"unexpected keyword arguments {sorted(extra)}")
-        if kwargs.get("render_mode") is not None or kwargs.get("save_video"):
-            raise NotImplementedError("rendering / video recording is not part of the HIP path")
-        args = {k: v for k, v in kwargs.items() if k in allowed}
-        args.setdefault("model_path", "./models/quadruped/scene.xml")
-        self._vec = POWalkingQuadrupedVecEnv(1, obs_window=obs_window, **args)
+        args = _facade_kwargs(kwargs, {"settling_time", "random_controls", "random_init", "reset_options", "model_path", "max_time",
+                                       "frame_skip", "device", "use_default_termination"})
+        self._vec = POWalkingQuadrupedVecEnv(1, obs_window=obs_window, auto_reset=False, **args)
         self.obs_window = obs_window
         self.action_space, self.observation_space = self._vec.action_space, self._vec.observation_space
         self.model = self._vec.model
@@ -325,12 +330,8 @@ class POWalkingQuadrupedEnv:
 
     def step(self, action):
         obs, rew, dones, infos = self._vec.step(np.asarray(action, np.float32)[None])
-        info = dict(infos[0])
-        term_obs = info.pop("terminal_observation", None)
-        info.pop("TimeLimit.truncated", None)
-        self.info = info
-        out = term_obs if term_obs is not None else obs[0]
-        return out.astype(np.float64), float(rew[0]), bool(dones[0]), False, self.info
+        self.info = dict(infos[0])
+        return obs[0].astype(np.float64), float(rew[0]), bool(dones[0]), False, self.info
 
     def close(self):
         self._vec.close()

@@ -141,6 +141,13 @@ class BatchedSim:
     def mapping(self) -> int:
         return int(self._lib.qg_get_mapping(self._h))
 
+    def set_task(self, task: QgTask):
+        """Replace the task constants of the live handle (``qg_set_task``): reward weights, terminations, auto-reset,
+        frame_skip -- what assigning ``env.reward_fns`` / ``env.termination_fns`` after construction does in the reference."""
+        check(self._lib.qg_set_task(self._h, C.byref(task)), "qg_set_task")
+        self.task = task
+        self.limit_substeps = int(self._lib.qg_time_limit_substeps(self.model.timestep, self.task.max_time))
+
     def set_track_ctrl(self, on: bool):
         check(self._lib.qg_set_track_ctrl(self._h, 1 if on else 0), "qg_set_track_ctrl")
 

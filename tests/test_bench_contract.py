@@ -66,13 +66,15 @@ def test_bench_prints_one_contract_line_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_rehearsal_on_one_gpu():
+@pytest.mark.parametrize("envs_per_gpu", [512, 32768])
+def test_bench_two_ranks_rehearsal_on_one_gpu(envs_per_gpu):
     """The N > 1 code path of bench.py (rank-local shards, per-step gather, max-over-ranks timing, one line from rank 0),
     launched exactly as the driver launches it; both ranks share GPU 0 and the exchange goes through gloo, because a one-GPU
-    box cannot host two RCCL ranks."""
+    box cannot host two RCCL ranks.  32 768 envs per rank is BASELINE config 4's per-GPU shard (262 144 envs over 8 GPUs, one
+    gather of the packed [32 768, 35] f32 rows per step)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "10",
-           "--envs-per-gpu", "512", "--rehearse-shared-gpu", "--no-cpu-baseline"]
+           "--envs-per-gpu", str(envs_per_gpu), "--rehearse-shared-gpu", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -80,7 +82,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     d = json.loads(lines[0])
     assert CONTRACT_KEYS <= set(d)
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["state_finite"] is True
-    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate
+    assert abs(d["value"] - 2 * envs_per_gpu / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate
+    assert d["config"]["envs_per_gpu"] == envs_per_gpu and d["config"]["ctrl_tracking"] is True
 
 
 @pytest.mark.gpu
@@ -88,7 +91,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
 def test_exchange_auto_reports_a_valid_line_whatever_the_graph_attempt_does(fault):
     """--exchange auto (the multi-GPU default) measures the eager loop first and then tries hipGraph replays under a watchdog.
     With a 1-rank RCCL group (--force-gather) on this box: the attempt succeeds; an injected exception falls back to the eager
-    line; an injected stall makes the watchdog print the eager line and end the process with exit code 0."""
+    line; an injected stall makes the watchdog print the eager line, marked `graph_stalled`, and end the process with a NON-ZERO
+    status (a hung GPU is not a success)."""
     env = dict(os.environ)
     if fault:
         env["QG_BENCH_GRAPH_FAULT"] = fault
@@ -96,10 +100,11 @@ def test_exchange_auto_reports_a_valid_line_whatever_the_graph_attempt_does(faul
     env["MASTER_PORT"] = str(_free_port())
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-gather", "--steps", "400", "--warmup", "40",
                           "--no-cpu-baseline", "--graph-timeout", "20"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.returncode == (3 if fault == "stall" else 0), out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    assert d.get("graph_stalled", False) is (fault == "stall")
     assert CONTRACT_KEYS <= set(d) and d["steps"] == 400 and d["n_gpus"] == 1
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     if fault is None:

@@ -114,8 +114,8 @@ def test_vec_env_protocol():
             assert infos[i]["terminal_observation"].shape == (33,) and infos[i]["TimeLimit.truncated"] is False
             assert not obs[i].any()                   # auto-reset: the returned obs is the reset obs (zeros)
     assert saw_done
-    with pytest.raises(NotImplementedError):
-        QuadrupedVecEnv(4, reward_fns={"mine": lambda v: 0.0})
+    with pytest.raises(ValueError, match="zero-argument callable"):
+        QuadrupedVecEnv(4, reward_fns={"mine": 3.0})          # neither a callable nor a named built-in
     assert env.env_is_wrapped(object) == [False] * 130 and len(env.get_attr("frame_skip")) == 130
     env.close()
 
@@ -134,4 +134,103 @@ def test_vec_env_tensor_path_and_imu_pack():
     assert np.allclose(p[:, 21], 1.0) and not p[:, 22].any()
     d = env.sync_data()
     assert d.qpos.shape == (256, 19) and np.allclose(d.time, 0.04)
+    env.close()
+
+
+def test_env_axis_array_keeps_one_value_per_env():
+    """The batched ``env.data`` view: reference-style expressions written for ONE robot (README.md:64-90) evaluate to one
+    value per env -- reductions without ``axis`` keep the env axis."""
+    from quadruped_gym_amd.envs.vec_env import CallableDataView, EnvAxisArray
+    n = 7
+    d = CallableDataView(n, 33)
+    rng = np.random.default_rng(0)
+    for k in ("qpos", "qvel", "ctrl", "act", "sensordata"):
+        d._store[k][:] = rng.normal(size=d._store[k].shape)
+    ctrl, qvel, qpos = d._store["ctrl"], d._store["qvel"], d._store["qpos"]
+    assert isinstance(d.qvel[0], EnvAxisArray) and np.array_equal(d.qvel[0], qvel[0])
+    assert np.allclose(-0.1 * np.sum(np.square(d.ctrl)), -0.1 * (ctrl ** 2).sum(0))
+    assert np.array_equal(d.qpos[2] < 0.2, qpos[2] < 0.2)
+    assert np.allclose(np.linalg.norm(d.qvel[0:3]), np.linalg.norm(qvel[0:3], axis=0))
+    assert np.allclose(np.dot(d.qvel[0:3], d.qvel[3:6]), (qvel[0:3] * qvel[3:6]).sum(0))
+    assert np.allclose(np.abs(d.ctrl).max(), np.abs(ctrl).max(0)) and np.allclose(np.mean(d.ctrl), ctrl.mean(0))
+    assert np.array_equal(np.any(d.qpos[7:] > 1.0), (qpos[7:] > 1.0).any(0))
+    assert d.ctrl.sum(axis=1).shape == (12,)                                  # an explicit axis is honoured as given
+    assert d.qpos[2].sum().shape == (n,)                                       # already one value per env: unchanged
+    d._cursor = 3                                                              # per-env evaluation: the reference's shapes
+    assert d.qpos.shape == (19,) and d.qpos.dtype == np.float64 and isinstance(d.time, float)
+    assert np.sum(np.square(d.ctrl)) == pytest.approx((ctrl[:, 3] ** 2).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["per_env", "batched"])
+def test_vec_env_runs_readme_callables_like_the_builtins(mode):
+    """README.md:64-90 verbatim (zero-arg lambdas over ``env.data``) on the batched env, N = 64: the host-evaluated
+    callables must reproduce the device built-ins of the same formulas -- reward, components, done, auto-reset -- over an
+    episode that ends both by `fall` and by the time limit."""
+    from quadruped_gym_amd.envs.vec_env import QuadrupedVecEnv
+    n = 64
+    ref = QuadrupedVecEnv(n, max_time=0.4, reward_fns={"forward": 1.0, "control_cost": -0.1, "alive_bonus": 1.0},
+                          termination_fns={"fall": 0.1}, random_init=True, seed=3)
+    env = QuadrupedVecEnv(n, max_time=0.4, random_init=True, seed=3, callable_mode=mode)
+
+    def forward_reward(env):
+        return env.data.qvel[0]
+
+    def control_cost(env):
+        return -0.1 * np.sum(np.square(env.data.ctrl))
+
+    def alive_bonus(env):
+        return 1.0
+
+    def fall_termination(env):
+        return env.data.qpos[2] < 0.1
+    env.reward_fns = {"forward": lambda: forward_reward(env), "control_cost": lambda: control_cost(env),
+                      "alive_bonus": lambda: alive_bonus(env)}                  # assigned after construction, README.md:74-78
+    env.termination_fns["fall"] = lambda: fall_termination(env)                 # README.md:89
+    assert not ref.reset().any() and not env.reset().any()
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for k in range(60):
+        a = rng.uniform(-1.3, 1.3, (n, 12)).astype(np.float32)
+        o1, r1, d1, i1 = ref.step(a)
+        o2, r2, d2, i2 = env.step(a)
+        assert np.array_equal(d1, d2), k
+        assert np.array_equal(o1, o2)                                           # same kernel, same states: identical bits
+        assert np.allclose(r1, r2, atol=2e-6)
+        for i in (0, n // 2, n - 1):
+            for key in ("forward", "control_cost", "alive_bonus"):
+                assert i1[i]["reward_components"][key] == pytest.approx(i2[i]["reward_components"][key], abs=2e-6)
+        for i in np.nonzero(d1)[0]:
+            assert np.array_equal(i1[i]["terminal_observation"], i2[i]["terminal_observation"])
+        n_done += int(d1.sum())
+    s1, s2 = ref._sim.get_state(), env._sim.get_state()
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[4], s2[4])        # the host-side masked reset = the in-kernel auto-reset
+    assert n_done >= n                                                           # every env finished at least once (0.4 s limit)
+    # dropping the default termination and the fall callable: nothing ends any more; a named built-in mixes with callables
+    del env.termination_fns["default"], env.termination_fns["fall"]
+    env.reward_fns["alive_bonus"] = 2.0
+    for k in range(60):
+        o2, r2, d2, i2 = env.step(np.zeros((n, 12), np.float32))
+        assert not d2.any()
+    assert i2[0]["alive_bonus"] == 2.0 and set(i2[0]["reward_components"]) == {"forward", "control_cost", "alive_bonus"}
+    ref.close(); env.close()
+
+
+@pytest.mark.gpu
+def test_walking_facades_refuse_custom_callables_and_do_not_auto_reset():
+    """walking_quad.py:11-12 forwards reward_fns / termination_fns to QuadrupedEnv, where they would replace the task's
+    reward; the device task layer refuses them rather than ignoring them.  A single robot is not auto-continued: after the
+    time limit it keeps reporting `terminated` until the caller resets (the reference's behaviour)."""
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedEnv, WalkingQuadrupedEnv
+    with pytest.raises(NotImplementedError, match="reward_fns"):
+        WalkingQuadrupedEnv(model_path="builtin", reward_fns={"x": lambda: 0.0})
+    with pytest.raises(NotImplementedError, match="termination_fns"):
+        POWalkingQuadrupedEnv(obs_window=2, model_path="builtin", termination_fns={"x": lambda: False})
+    env = WalkingQuadrupedEnv(model_path="builtin", max_time=0.03)
+    env.reset()
+    flags = [env.step(np.zeros(12, np.float32))[2] for _ in range(8)]
+    assert flags == [False, False, False, True, True, True, True, True]      # 16 substeps > 0.03 s: stays terminated, no silent reset
+    assert env._vec._sim.get_state()[4][0] == 32
+    obs, _ = env.reset()
+    assert env._vec._sim.get_state()[4][0] == 0 and not obs.any()
     env.close()

@@ -14,10 +14,14 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_vectors.npz")
 
 # ---- stated tolerances: |gpu - oracle| <= atol + rtol * |oracle| after one env-step ----------
+# The absolute terms are <= 5x the largest error MEASURED over 4096 seeded states per frame_skip and every work mapping
+# (tools/parity_report.py -> profiles/r02/parity_report.txt; frame_skip 4: qpos 1.2e-6, qvel 4.3e-4, act 8.2e-8, obs 7.5e-5,
+# accelerometer 5.3e-3 m/s^2, reward 3.5e-6), so a regression that costs an order of magnitude of accuracy fails.  frame_skip
+# 20 compounds 20 substeps and a contact can switch inside the step (measured maxima qpos 1.5e-4, qvel 7.7e-2, obs 5.8e-4,
+# accelerometer 0.85, reward 3.0e-4).
 TOL = {
-    # frame_skip 4 (case A)                     frame_skip 20 (case B): error grows with the substeps
-    "A": dict(qpos=(2e-5, 1e-5), qvel=(5e-3, 2e-3), act=(1e-6, 1e-6), obs=(5e-3, 2e-3), accel=(0.25, 5e-3), reward=(5e-3, 1e-3)),
-    "B": dict(qpos=(4e-4, 1e-4), qvel=(5e-2, 2e-2), act=(1e-6, 1e-6), obs=(5e-2, 2e-2), accel=(2.0, 5e-2), reward=(5e-2, 1e-2)),
+    "A": dict(qpos=(5e-6, 2e-6), qvel=(2e-3, 1e-4), act=(4e-7, 1e-6), obs=(3.5e-4, 1e-4), accel=(0.025, 1e-3), reward=(1.5e-5, 1e-5)),
+    "B": dict(qpos=(4e-4, 1e-4), qvel=(5e-2, 2e-2), act=(6e-7, 1e-6), obs=(3e-3, 2e-3), accel=(2.0, 5e-2), reward=(1.5e-3, 1e-3)),
 }
 
 
@@ -474,4 +478,44 @@ def test_tiny_and_ragged_batches(oracle, mapping, n):
     close(rew, rew_o, t["reward"], "reward")
     close(q1, q_o, t["qpos"], "qpos")
     close(v1, v_o, t["qvel"], "qvel")
+    sim.close()
+
+
+def test_reset_is_ordered_after_steps_on_a_side_stream():
+    """include/quadgym.h ordering contract: qg_reset waits for device-pointer steps still in flight on ANY stream of the
+    device before it rewrites the state (it runs on the library's own non-blocking stream).  Many steps queued on a side
+    stream, then reset(): every env must stand at qpos0 with a zero clock, nothing of the steps may land afterwards."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    n = 32768
+    sim = BatchedSim(n)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    acts = torch.rand((n, 12), device=dev) * 2 - 1
+    packed = torch.empty((n, 35), device=dev)
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        for _ in range(200):                      # ~6 ms of queued kernels: the host gets far ahead of the device
+            sim.step_device_packed(acts, packed, stream=side)
+        sim.reset()
+        qpos, qvel, act, ctrl, nstep = sim.get_state()
+        assert not nstep.any() and not qvel.any() and not act.any()
+        assert np.array_equal(qpos, np.tile(np.array(sim.model.qpos0[:], np.float32), (n, 1)))
+    sim.close()
+
+
+def test_masked_reset_keeps_the_batch_seed(oracle):
+    """The seed keys the reset streams of every env (auto-resets included); a masked reset must not re-key the batch: it
+    draws from the seed of the last whole-batch reset, whatever seed argument it is given."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n, base = 64, 40
+    sim = BatchedSim(n, env_index_base=base)
+    sim.reset(seed=1234, flags=_abi.RESET_RANDOM_YAW)             # episode counter 0 -> 1
+    mask = np.zeros(n, np.uint8)
+    mask[[3, 17]] = 1
+    sim.reset(mask=mask, seed=999, flags=_abi.RESET_RANDOM_YAW)   # counter 1 for the two, seed stays 1234
+    qpos = sim.get_state()[0]
+    for i in range(n):
+        a = 2 * np.pi * oracle.uniform(1234, base + i, 1 if mask[i] else 0)
+        assert np.allclose(qpos[i, [3, 6]], [np.cos(a / 2), np.sin(a / 2)], atol=2e-7), i
     sim.close()

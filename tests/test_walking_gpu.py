@@ -140,3 +140,59 @@ def test_single_env_facade_has_reference_signature():
     assert set(info) == set(REWARD_KEYS) and trunc is False and isinstance(r, float)
     assert np.isfinite(r) and r == pytest.approx(sum(info.values()), rel=1e-5)
     env.close()
+
+
+def test_zero_norm_direction_is_nan_as_in_the_reference():
+    """math_utils.unit() of a zero vector is NaN (math_utils.py:7-8) and that NaN reaches progress_direction_reward_local and
+    the total (walking_quad.py:197-205,422).  The device code is compiled with -ffinite-math-only, so the kernel produces that
+    NaN explicitly (quiet-NaN bit pattern through an integer select): a zero command must read NaN in exactly those two
+    places, every other component stays finite, and envs with a non-zero command and a moving body stay finite."""
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    n = 8
+    env = WalkingQuadrupedVecEnv(n, max_time=100.0)
+    vel = np.tile(np.array([[0.3, 0.1]], np.float32), (n, 1))
+    vel[2] = 0.0                                            # zero commanded velocity: unit(command) is NaN
+    env.set_commands(vel, np.tile(np.array([[1.0, 0.0]], np.float32), (n, 1)))
+    env.reset()
+    rng = np.random.default_rng(1)
+    for _ in range(40):                                     # asymmetric actions: the body picks up a local xy velocity
+        obs, rew, dones, infos = env.step(rng.uniform(-1, 1, (n, 12)).astype(np.float32))
+    comps = env.last_components
+    assert np.isnan(comps[2, 2]) and np.isnan(rew[2])
+    others = np.delete(np.arange(11), 2)
+    assert np.isfinite(comps[2, others]).all()
+    keep = np.delete(np.arange(n), 2)
+    assert np.isfinite(comps[keep]).all() and np.isfinite(rew[keep]).all()
+    env.close()
+
+
+def test_walk_destroy_restores_the_sim():
+    """qg_walk_create switches the bound sim's flip termination and data.ctrl tracking on; qg_walk_destroy must hand the sim
+    back as it found it (include/quadgym.h): an upside-down robot terminates while the layer is bound and not afterwards."""
+    import ctypes as C
+    from quadruped_gym_amd._abi import check, load_library
+    from quadruped_gym_amd.sim import BatchedSim
+    lib = load_library()
+    sim = BatchedSim(4)
+    sim.set_track_ctrl(False)
+
+    def flipped_done():
+        qpos = sim.get_state()[0]
+        qpos[:, 2] = 0.3
+        qpos[1, 3:7] = [0, 1, 0, 0]                         # env 1 rolled by 180 degrees
+        sim.set_state(qpos=qpos, qvel=np.zeros((4, 18), np.float32))
+        return sim.step(np.zeros((4, 12), np.float32))[2]
+    assert not flipped_done().any()                         # base task: no flip termination
+    w = C.c_void_p()
+    check(lib.qg_walk_create(sim._h, None, C.byref(w)), "qg_walk_create")
+    d = flipped_done()
+    assert d[1] and d.sum() == 1
+    a = np.full((4, 12), 0.25, np.float32)
+    sim.step(a)
+    assert np.array_equal(sim.get_state()[3], a)            # data.ctrl tracked while the layer is bound
+    check(lib.qg_walk_destroy(w), "qg_walk_destroy")
+    assert not flipped_done().any()
+    before = sim.get_state()[3]
+    sim.step(np.full((4, 12), -0.5, np.float32))
+    assert np.array_equal(sim.get_state()[3], before)       # tracking is off again, as the caller had set it
+    sim.close()

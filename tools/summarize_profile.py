@@ -25,7 +25,7 @@ def main(src, dst_prefix):
                 r[0] = short(r[0])
                 w.writerow(r)
     pmc = {}
-    for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_flops"):
         for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             acc = {}
             for row in csv.DictReader(open(path)):
@@ -40,6 +40,8 @@ def main(src, dst_prefix):
         out["hbm_bytes_per_launch"] = {"read": 2 * pmc["FETCH_SIZE"] * 1024, "write": pmc["WRITE_SIZE"] * 1024,
                                        "total": (2 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024,
                                        "correction": "FETCH_SIZE x2 (gfx950), KiB -> bytes"}
+    if "SQ_INSTS_VALU_FLOPS_FP32" in pmc:
+        out["fp32"] = {k: pmc[k] for k in pmc if k.startswith("SQ_INSTS_VALU_") and ("F32" in k or "FP32" in k)}
     if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
         out["valu_insts_per_wave"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
     json.dump(out, open(dst_prefix + "_pmc.json", "w"), indent=1)
