@@ -69,32 +69,25 @@ def cpu_baseline(n_envs: int, frame_skip: int, seconds: float):
     out = {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
            "sample": f"{n} envs x {steps} env-steps (frame_skip {frame_skip}) of the same workload, single thread, {dt:.1f} s",
            "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
-    # all host cores: independent shards in threads (ctypes releases the GIL inside the C call)
+    # all host cores: the same workload at the bench's own batch size, env range partitioned over every core this process may
+    # use (OpenMP inside the oracle's C batch loop; bit-identical to the single-thread run)
     try:
-        import threading
-        nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))   # every core this process may use
-        batches = []
-        for i in range(nthr):
-            b = O.Batch(model, task, n)
-            b.reset()
-            batches.append(b)
-        counts = [0] * nthr
-        stop = time.perf_counter() + max(2.0, seconds / 3)
-
-        def work(i):
-            k = 0
-            while time.perf_counter() < stop:
-                _, _, d, _ = batches[i].step(acts[k % 8])
-                if d.any():
-                    batches[i].reset(mask=d)
-                k += 1
-            counts[i] = k
+        nthr = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        nb = max(n_envs, 16 * nthr)
+        big = O.Batch(model, task, nb)
+        big.reset()
+        acts_b = rng.uniform(-1, 1, (4, nb, 12))
+        big.step(acts_b[0], threads=nthr)            # warm (thread pool start-up)
         t1 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(i,)) for i in range(nthr)]
-        [t.start() for t in th]
-        [t.join() for t in th]
+        k = 0
+        budget = max(2.0, seconds / 3)
+        while time.perf_counter() - t1 < budget:
+            _, _, d, _ = big.step(acts_b[k % 4], threads=nthr)
+            if d.any():
+                big.reset(mask=d)
+            k += 1
         dt2 = time.perf_counter() - t1
-        out["all_cores"] = {"value": n * sum(counts) / dt2, "cores": nthr}
+        out["all_cores"] = {"value": nb * k / dt2, "cores": nthr, "sample": f"{nb} envs x {k} env-steps, OpenMP static partition, {dt2:.1f} s"}
     except Exception as exc:       # the single-thread number stands on its own
         out["all_cores"] = {"error": repr(exc)}
     try:

@@ -62,6 +62,8 @@ def lib():
                                C.POINTER(C.c_int32), dp]
         L.qgo_step_batch.argtypes = [C.POINTER(QgModel), C.POINTER(QgTask), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.qgo_step_batch_mt.argtypes = [C.POINTER(QgModel), C.POINTER(QgTask), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         assert L.qgo_sizeof_env() == C.sizeof(Env), (L.qgo_sizeof_env(), C.sizeof(Env))
         assert L.qgo_sizeof_diag() == C.sizeof(Diag)
         assert L.qgo_sizeof_model() == C.sizeof(QgModel), (L.qgo_sizeof_model(), C.sizeof(QgModel))
@@ -206,14 +208,19 @@ class Batch:
         nstep = np.array([self.envs[i].nstep for i in range(self.n)], dtype=np.int32)
         return f[:, :NQ].copy(), f[:, NQ:NQ + NV].copy(), f[:, NQ + NV:NQ + NV + NU].copy(), f[:, NQ + NV + NU:].copy(), nstep
 
-    def step(self, actions):
+    def step(self, actions, threads: int = 1):
         a = np.ascontiguousarray(actions, dtype=np.float64)
         assert a.shape == (self.n, NU)
         obs = np.zeros((self.n, self.od)); rew = np.zeros(self.n); done = np.zeros(self.n, dtype=np.int32)
         comps = np.zeros((self.n, 3))
-        rc = lib().qgo_step_batch(C.byref(self.model), C.byref(self.task), C.addressof(self.envs), self.n,
-                                  a.ctypes.data, self.limit, obs.ctypes.data, rew.ctypes.data, done.ctypes.data,
-                                  comps.ctypes.data)
+        if threads > 1:
+            rc = lib().qgo_step_batch_mt(C.byref(self.model), C.byref(self.task), C.addressof(self.envs), self.n,
+                                         a.ctypes.data, self.limit, obs.ctypes.data, rew.ctypes.data, done.ctypes.data,
+                                         comps.ctypes.data, int(threads))
+        else:
+            rc = lib().qgo_step_batch(C.byref(self.model), C.byref(self.task), C.addressof(self.envs), self.n,
+                                      a.ctypes.data, self.limit, obs.ctypes.data, rew.ctypes.data, done.ctypes.data,
+                                      comps.ctypes.data)
         if rc != 0:
             raise FloatingPointError(f"oracle linear solve failed (env {-rc - 1})")
         return obs, rew, done.astype(bool), comps

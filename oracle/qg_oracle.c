@@ -625,6 +625,22 @@ int qgo_step_batch(const qg_model *m, const qg_task *t, qgo_env *envs, int32_t n
     return 0;
 }
 
+/* the same over `nthreads` host threads (OpenMP, static partition of the env range): the all-cores row of the CPU baseline.
+ * Envs are independent, so the results are those of qgo_step_batch bit for bit. */
+int qgo_step_batch_mt(const qg_model *m, const qg_task *t, qgo_env *envs, int32_t n, const double *actions,
+                      int64_t limit_substeps, double *obs, double *reward, int32_t *done, double *comps, int32_t nthreads) {
+    int od = t->obs_mode == QG_OBS_IMU ? 21 : QG_NSENSOR;
+    int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int i = 0; i < n; i++)
+        if (qgo_step(m, t, &envs[i], actions + (size_t)i * NU, limit_substeps, obs + (size_t)i * od, reward + i,
+                     done + i, comps ? comps + (size_t)i * 3 : NULL) != 0) {
+#pragma omp atomic write
+            bad = 1 + i;
+        }
+    return bad ? -bad : 0;
+}
+
 /* ------------------------------------------------- probes for the KAT suite */
 int qgo_default_model(qg_model *out) {
     static const qg_model def = QG_MODEL_DEFAULT_INIT;

@@ -36,6 +36,8 @@
 #include "qg_model_baked.h"
 
 #define DEV __device__ __forceinline__
+#define QG_STR2(x) #x
+#define QG_STR(x) QG_STR2(x)
 
 // ------------------------------------------------------------------------------------------
 // model tables.  Two kernel variants: BAKED reads the default robot's constants from a `const`
@@ -242,6 +244,8 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
 DEV float uniform24s(uint64_t seed, uint64_t env_index, uint64_t counter, uint32_t stream) {
     return uniform24(seed + 0xA0761D6478BD642Full * (uint64_t)stream, env_index, counter);
 }
+#include "qg_walk_dev.h"     // walking task layer: per-env device functions used by the fused walking variant of the quad kernel
+
 // start value of hinge j at a reset with QG_RESET_JOINT_JITTER: qpos0 + jitter * U(-1, 1), kept inside the joint range
 DEV float jittered_hinge(float q0, float lo, float hi, float jitter, uint64_t seed, uint64_t env_index, int episode, int j) {
     float u = uniform24s(seed, env_index, (uint64_t)episode, QG_STREAM_HINGE + (uint32_t)j);
@@ -263,9 +267,12 @@ template <class T> DEV void contact_point(V3T<T> r, V3T<T> nl, T zb, T &wsum, V3
     wsum += pen;
     s = fma3(pen, r, s);
 }
+// The implicit (velocity-proportional) part of one aggregated contact: h * (ct * point-mass(P) + (cn - ct) * a a^T), a = [P x n; n],
+// kept as five numbers until the composite inertia it belongs to is assembled.
+template <class T> struct ContactDampT { T mc, w; V3T<T> P; };
 template <class T>
-DEV void contact_finish(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp, float mu, float h,
-                        SVT<T> &f_ext, Sym6T<T> &A) {
+DEV void contact_eval(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp, float mu, float h,
+                      SVT<T> &f_ext, ContactDampT<T> &cd) {
     const T zero = T(0.f);
     auto active = wsum > zero;
     T W = kc * wsum;
@@ -288,7 +295,16 @@ DEV void contact_finish(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, S
     V3T<T> F = Fn * n - ct * vt;
     f_ext.a = cross(P, F);
     f_ext.l = F;
-    add_contact_damping(A, h * ct, h * (cn - ct), P, n);
+    cd.mc = h * ct;
+    cd.w = h * (cn - ct);
+    cd.P = P;
+}
+template <class T>
+DEV void contact_finish(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp, float mu, float h,
+                        SVT<T> &f_ext, Sym6T<T> &A) {
+    ContactDampT<T> cd;
+    contact_eval(wsum, s, E, p, n, v, kc, cmax, inv_ramp, mu, h, f_ext, cd);
+    add_contact_damping(A, cd.mc, cd.w, cd.P, n);
 }
 template <class T, int NCP>
 DEV void body_contact(const float (*cp)[3], const FrT<T> &E, V3T<T> p, T z_origin, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp,
@@ -300,6 +316,25 @@ DEV void body_contact(const float (*cp)[3], const FrT<T> &E, V3T<T> p, T z_origi
 #pragma unroll
     for (int i = 0; i < NCP; ++i) contact_point(ld3t<T>(cp[i]), nl, zb, wsum, s);
     contact_finish(wsum, s, E, p, n, v, kc, cmax, inv_ramp, mu, h, f_ext, A);
+}
+template <class T, int NCP>
+DEV void body_contact_compact(const float (*cp)[3], const FrT<T> &E, V3T<T> p, T z_origin, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp,
+                              float margin, float mu, float h, SVT<T> &f_ext, ContactDampT<T> &cd) {
+    V3T<T> nl = rotT(E, n);                 // world up in the body's own axes
+    T wsum = T(0.f);
+    V3T<T> s = v3<T>(T(0.f), T(0.f), T(0.f));
+    T zb = T(margin) - z_origin;
+#pragma unroll
+    for (int i = 0; i < NCP; ++i) contact_point(ld3t<T>(cp[i]), nl, zb, wsum, s);
+    contact_eval(wsum, s, E, p, n, v, kc, cmax, inv_ramp, mu, h, f_ext, cd);
+}
+// A += (rigid inertia B about the FRAME origin)
+template <class T> DEV void add_rigid(Sym6T<T> &A, const RigidT<T> &B) {
+    add(A.AA, B.I);
+    A.AL.r0.y -= B.h.z; A.AL.r0.z += B.h.y;
+    A.AL.r1.x += B.h.z; A.AL.r1.z -= B.h.x;
+    A.AL.r2.x -= B.h.y; A.AL.r2.y += B.h.x;
+    A.LL.xx += B.m; A.LL.yy += B.m; A.LL.zz += B.m;
 }
 
 struct BaseState { V3 pw; float qw, qx, qy, qz; V3 vw; V3 wb; };
@@ -354,7 +389,10 @@ DEV void frame_body(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic
 // Out: leg composite inertia Ic and force fc (to be added to the base rows), the base coupling
 // columns F[j], the leg block H = [[Hd0,H01,H02],[.,Hd1,H12],[.,.,Hd2]] and the right-hand side b.
 // ------------------------------------------------------------------------------------------
-template <class T, bool BAKED, bool QUAD, bool CULL_FEMUR = false>
+// COMPACT: keep (rigid inertia, contact-damping numbers) per link -- 14 live values instead of a 21-value 6x6 -- and assemble the
+// 6x6 forms in the backward pass straight into the composite.  Same arithmetic per term, different summation order; used by the
+// register-capped (3 and 4 waves per SIMD) instantiations of the one-leg-per-lane kernel.
+template <class T, bool BAKED, bool QUAD, bool CULL_FEMUR = false, bool COMPACT = false>
 DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3], const T act[3], const BaseCtx &bc, float zbase_f,
                   float h, Sym6T<T> &Ic, SVT<T> &fc, SVT<T> F[3], T Hd[3], T &H01, T &H02, T &H12, T bj[3]) {
     const T zero = T(0.f);
@@ -363,7 +401,11 @@ DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3]
     const T zbase = T(zbase_f);
     SVT<T> vp = splat6<T>(bc.V0), ap = splat6<T>(bc.A0);
     SVT<T> S[3], f[3];
-    Sym6T<T> Ag[3];
+    // per link: rigid inertia (h, I; the mass is a constant) and the five numbers of its contact's implicit damping -- the 6x6
+    // forms are assembled in the backward pass straight into the composite (14 live values per link instead of 21)
+    RigidT<T> Bs[3];
+    ContactDampT<T> Cd[3];
+    Sym6T<T> Ag[3];                 // only one of the two forms is live in an instantiation
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const KLink &L = link_of<BAKED>(C, k, i);
@@ -403,7 +445,12 @@ DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3]
         SVT<T> Iv = mul(Bi, v), Ia = mul(Bi, a);
         f[i].a = Ia.a + cross(v.a, Iv.a) + cross(v.l, Iv.l);
         f[i].l = Ia.l + cross(v.a, Iv.l);
-        Ag[i] = sym6_of(Bi);
+        if constexpr (COMPACT) {
+            Bs[i] = Bi;
+            Cd[i].mc = zero; Cd[i].w = zero; Cd[i].P = v3<T>(zero, zero, zero);
+        } else {
+            Ag[i] = sym6_of(Bi);
+        }
         T zo = zbase + dot(nb, p);
         bool may = true;
         if (CULL_FEMUR && i == 0) {
@@ -417,26 +464,45 @@ DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3]
         }
         if (may) {
             SVT<T> fe;
-            body_contact<T, QGK_CP_LINK>(L.cp, E, p, zo, nb, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
-                                         C.contact_margin, C.contact_mu, h, fe, Ag[i]);
+            if constexpr (COMPACT)
+                body_contact_compact<T, QGK_CP_LINK>(L.cp, E, p, zo, nb, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
+                                                     C.contact_margin, C.contact_mu, h, fe, Cd[i]);
+            else
+                body_contact<T, QGK_CP_LINK>(L.cp, E, p, zo, nb, v, C.contact_k, C.contact_c, C.contact_inv_ramp,
+                                             C.contact_margin, C.contact_mu, h, fe, Ag[i]);
             f[i].a = f[i].a - fe.a;
             f[i].l = f[i].l - fe.l;
         }
         Ep = E; pp = p; vp = v; ap = a;
     }
     // backward pass: composite inertias (mass-matrix columns) and bias torques
-    Ic = Ag[2];
+    if constexpr (COMPACT) {
+        Ic = sym6_of(Bs[2]);
+        add_contact_damping(Ic, Cd[2].mc, Cd[2].w, Cd[2].P, nb);
+    } else {
+        Ic = Ag[2];
+    }
     fc = f[2];
     F[2] = mul(Ic, S[2]);
     T H22 = dot(S[2], F[2]), t2 = dot(S[2], fc);
     H12 = dot(S[1], F[2]);
     H02 = dot(S[0], F[2]);
-    add(Ic, Ag[1]);
+    if constexpr (COMPACT) {
+        add_rigid(Ic, Bs[1]);
+        add_contact_damping(Ic, Cd[1].mc, Cd[1].w, Cd[1].P, nb);
+    } else {
+        add(Ic, Ag[1]);
+    }
     fc = fc + f[1];
     F[1] = mul(Ic, S[1]);
     T H11 = dot(S[1], F[1]), t1 = dot(S[1], fc);
     H01 = dot(S[0], F[1]);
-    add(Ic, Ag[0]);
+    if constexpr (COMPACT) {
+        add_rigid(Ic, Bs[0]);
+        add_contact_damping(Ic, Cd[0].mc, Cd[0].w, Cd[0].P, nb);
+    } else {
+        add(Ic, Ag[0]);
+    }
     fc = fc + f[0];
     F[0] = mul(Ic, S[0]);
     T H00 = dot(S[0], F[0]), t0 = dot(S[0], fc);
@@ -880,7 +946,7 @@ struct LegState { float q[3], qd[3], act[3], u[3]; };
 // share a SIMD (register cap 256), costs ~2 % when a wave has the register file to itself.
 // BAKED: the compiled-in robot, constants are literals and the lane works in its leg's quarter-turn frame.  Otherwise `C`
 // is the model table staged in LDS and every lane reads the constants of its own leg (k) from it -- any model numbers.
-template <bool BAKED, bool LOWREG>
+template <bool BAKED, bool LOWREG, bool DIET = false>
 DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
     const float h = C.h;
     const BaseCtx bc0 = base_prelude(C, B);
@@ -909,10 +975,10 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         if constexpr (BAKED) {
             // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
             Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<float, true, true, LOWREG>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+            leg_pass<float, true, true, LOWREG, DIET>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         } else {
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<float, false, false, LOWREG>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+            leg_pass<float, false, false, LOWREG, DIET>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
         }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
@@ -983,7 +1049,11 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 
 // WPE = waves per SIMD the register allocation is capped for: 1 (all 512 registers) is fastest while the grid has at
 // most one wave per SIMD (n <= 16384); 2 lets a second wave share the SIMD once the grid is larger.
-template <int WPE, bool BAKED>
+// WALK: the walking task layer fused in (qg_walk_dev.h) -- the whole WalkingQuadrupedEnv.step (walking_quad.py:128-148) is this
+// one launch: settling-time action mask and the estimator update of the lane's three control channels in the prologue (they
+// need data.ctrl of the PREVIOUS step, which is still in place there), ideal-position integration, the eleven reward terms and
+// the episode bookkeeping in the epilogue on the sensor row the wave has just staged in LDS.
+template <int WPE, bool BAKED, bool WALK = false>
 __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P) {
     __shared__ float tile[QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
@@ -1010,22 +1080,41 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
     B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
-    int nstep = P.st.nstep[env];
     LegState L;
-    float aclip[3];
-    float ssq = 0.f;
+    const int nstep0 = P.st.nstep[env];
+    float aclip0[3];
+    bool settle = false;
+    int calls = 0;
+    WalkEnvIn win = {};
+    if constexpr (WALK) {
+        settle = nstep0 < P.walk->P.settle_substeps;                // data.time < settling_time (walking_quad.py:142-143)
+        calls = P.walk->S.calls[env];
+    }
+    if constexpr (WALK) {
+        // the estimator takes data.ctrl of the PREVIOUS step (walking_quad.py:136), still in place here; its loads go out together
+        // with the state loads around them
+        const KWalkDev &W = *P.walk;
+        const int tt[3] = {(3 * k + 0) * n + env, (3 * k + 1) * n + env, (3 * k + 2) * n + env};
+        const float xx[3] = {P.st.ctrl[tt[0]], P.st.ctrl[tt[1]], P.st.ctrl[tt[2]]};
+        if (live) walk_estimator_update_n<3>(W.P, W.S, n, tt, xx, calls);
+        if (live && k == 0) win = walk_env_load(W.S, n, env);       // what the reward epilogue reads: fetched now, behind the physics
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = 3 * k + i;
-        float a = fminf(fmaxf(P.actions[(size_t)env * 12 + j], -1.f), 1.f);    // quadruped.py:160
-        aclip[i] = a;
-        ssq = fmaf(a, a, ssq);
+        float a_in = P.actions[(size_t)env * 12 + j];
+        if constexpr (WALK) {
+            const KWalkDev &W = *P.walk;
+            if (settle) a_in = W.P.joint_centers[j];                 // the joint centres while the robot settles
+            if (live) W.S.eff_actions[(size_t)env * 12 + j] = a_in;  // the action actually applied (read again by the PO pack)
+        }
+        float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
+        aclip0[i] = a;
         L.u[i] = fminf(fmaxf(a, link_of<BAKED>(C, k, i).ctrl_lo), link_of<BAKED>(C, k, i).ctrl_hi);
         L.q[i] = P.st.qpos[(7 + j) * n + env];
         L.qd[i] = P.st.qvel[(6 + j) * n + env];
         L.act[i] = P.st.act[j * n + env];
     }
-    ssq = quad_sum(ssq);
 
     // the sensor values of the step go straight into this env's row of the output tile (full 33-value layout; the
     // 21-value pack is compacted below)
@@ -1033,14 +1122,75 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
     float zaxis_z = 1.f;
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
+    // Un-lagged sensors (task.sensor_lag = 0) take one extra forward pass whose state changes are discarded: the same loop body
+    // runs once more with the state parked in LDS meanwhile -- one copy of the substep code and no extra live registers.
+    // DIET (register caps for three / four waves per SIMD, QG_QUAD_WPE=3|4): measured NOT to pay -- 196 vs 200 us at 262 144 envs,
+    // slower below (profiles/r02/wpe_ab.txt) -- kept selectable so the measurement can be repeated.  What it changes: one copy of
+    // the substep code also for un-lagged sensors (state parked in LDS during the extra pass), the quarter-turn products are
+    // recomputed per substep instead of hoisted, the epilogue's addresses / clipped action / substep counter are re-derived after
+    // the loop instead of carried through it (60 VGPRs of hoisted store addresses, tools/asm_liveness.py), compact per-link
+    // inertias in leg_pass.
+    constexpr bool DIET = WPE > 2;
+    int env_e = env, k_e = k;
+    int nstep;
+    float aclip[3];
+    if constexpr (!DIET) {
+        // Code placement: a wave that is alone on its SIMD is sensitive to where the 14 KB loop body falls relative to the
+        // instruction-fetch lines -- the same loop, shifted by one dword through an unrelated edit of the prologue, measured
+        // 18.57 instead of 18.36 us per launch at 4096 envs (same-box A/B of eight paddings).  Pinning the loop to a 64-byte
+        // boundary makes its layout independent of what precedes it.
+        asm volatile(".p2align 6");
+#ifdef QG_EXP_PAD
+#pragma unroll
+        for (int q = 0; q < QG_EXP_PAD; ++q) asm volatile("s_nop 0");
+#endif
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
-    nstep += fs;
-    if (!lag) {
-        BaseState B2 = B;
-        LegState L2 = L;
-        substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B2, L2, true, srow, k, zaxis_z);
+        for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
+        if (!lag) {   // un-lagged sensors (task.sensor_lag = 0): one extra forward pass on a scratch copy of the state
+            BaseState B2 = B;
+            LegState L2 = L;
+            substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B2, L2, true, srow, k, zaxis_z);
+        }
+        nstep = nstep0 + fs;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) aclip[i] = aclip0[i];
+    } else {
+        __shared__ float park[25 * QGK_WAVE];
+        const int iters = lag ? fs : fs + 1;
+#pragma unroll 1
+        for (int s = 0; s < iters; ++s) {
+            const bool extra = s == fs;
+            if (extra) {
+                const float keep[25] = {B.pw.x, B.pw.y, B.pw.z, B.qw, B.qx, B.qy, B.qz, B.vw.x, B.vw.y, B.vw.z, B.wb.x, B.wb.y, B.wb.z,
+                                        L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2], L.act[0], L.act[1], L.act[2], L.u[0], L.u[1], L.u[2]};
+#pragma unroll
+                for (int j = 0; j < 25; ++j) park[j * QGK_WAVE + lane] = keep[j];
+            }
+            float cm_s = cm, sm_s = sm;
+            asm volatile("" : "+v"(cm_s), "+v"(sm_s));
+            substep_quad<BAKED, true, true>(C, cm_s, sm_s, B, L, lag ? (s == fs - 1) : extra, srow, k, zaxis_z);
+            if (extra) {
+                float keep[25];
+#pragma unroll
+                for (int j = 0; j < 25; ++j) keep[j] = park[j * QGK_WAVE + lane];
+                B.pw = v3(keep[0], keep[1], keep[2]); B.qw = keep[3]; B.qx = keep[4]; B.qy = keep[5]; B.qz = keep[6];
+                B.vw = v3(keep[7], keep[8], keep[9]); B.wb = v3(keep[10], keep[11], keep[12]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { L.q[i] = keep[13 + i]; L.qd[i] = keep[16 + i]; L.act[i] = keep[19 + i]; L.u[i] = keep[22 + i]; }
+            }
+        }
+        asm volatile("" : "+v"(env_e), "+v"(k_e));
+        nstep = P.st.nstep[env_e] + fs;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float *asrc = WALK ? P.walk->S.eff_actions : P.actions;
+            aclip[i] = fminf(fmaxf(asrc[(size_t)env_e * 12 + 3 * k_e + i], -1.f), 1.f);     // quadruped.py:160
+        }
     }
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ssq = fmaf(aclip[i], aclip[i], ssq);
+    ssq = quad_sum(ssq);
 
     float c_fwd = T->w_forward * B.vw.x;
     float c_ctl = T->w_ctrl * ssq;
@@ -1075,15 +1225,29 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
             }
         }
     }
-    const bool lead = live && k == 0;
+    const bool lead = live && k_e == 0;
     if (lead && !P.packed) {
-        P.reward[env] = reward;
-        P.done[env] = done ? 1 : 0;
+        if constexpr (!WALK) P.reward[env_e] = reward;
+        P.done[env_e] = done ? 1 : 0;
+    }
+    if constexpr (WALK) {
+        const KWalkDev &W = *P.walk;
+        WalkSums sum = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) walk_channel_terms(W.P, W.S, n, env_e, 3 * k_e + i, aclip[i], sum);
+        }
+        sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
+        if (lead) {
+            // the env's episode counter has not been advanced yet: it is the key of the episode that begins if this one ends
+            walk_reward_env(W.P, W.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, P.walk_comps, P.walk_sample, P.seed,
+                            P.env_index_base, P.st.episode[env_e]);
+        }
     }
     if (lead && P.comps) {
-        P.comps[(size_t)env * 3 + 0] = c_fwd;
-        P.comps[(size_t)env * 3 + 1] = c_ctl;
-        P.comps[(size_t)env * 3 + 2] = c_alive;
+        P.comps[(size_t)env_e * 3 + 0] = c_fwd;
+        P.comps[(size_t)env_e * 3 + 1] = c_ctl;
+        P.comps[(size_t)env_e * 3 + 2] = c_alive;
     }
 
     const bool rst = done && T->auto_reset;
@@ -1091,7 +1255,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
         B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
         if (T->reset_flags & 1u) {
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env_e, (uint64_t)P.st.episode[env_e]);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
             B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
@@ -1101,21 +1265,21 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         nstep = 0;
     }
     if (lead) {
-        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
-        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
-        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
-        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
-        P.st.nstep[env] = nstep;
-        if (rst) P.st.episode[env] += 1;
+        P.st.qpos[0 * n + env_e] = B.pw.x; P.st.qpos[1 * n + env_e] = B.pw.y; P.st.qpos[2 * n + env_e] = B.pw.z;
+        P.st.qpos[3 * n + env_e] = B.qw; P.st.qpos[4 * n + env_e] = B.qx; P.st.qpos[5 * n + env_e] = B.qy; P.st.qpos[6 * n + env_e] = B.qz;
+        P.st.qvel[0 * n + env_e] = B.vw.x; P.st.qvel[1 * n + env_e] = B.vw.y; P.st.qvel[2 * n + env_e] = B.vw.z;
+        P.st.qvel[3 * n + env_e] = B.wb.x; P.st.qvel[4 * n + env_e] = B.wb.y; P.st.qvel[5 * n + env_e] = B.wb.z;
+        P.st.nstep[env_e] = nstep;
+        if (rst) P.st.episode[env_e] += 1;
     }
     if (live) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int j = 3 * k + i;
-            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : L.q[i];
-            P.st.qvel[(6 + j) * n + env] = rst ? 0.f : L.qd[i];
-            P.st.act[j * n + env] = rst ? 0.f : L.act[i];
-            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
+            const int j = 3 * k_e + i;
+            P.st.qpos[(7 + j) * n + env_e] = rst ? C.qpos0[7 + (BAKED ? i : j)] : L.q[i];
+            P.st.qvel[(6 + j) * n + env_e] = rst ? 0.f : L.qd[i];
+            P.st.act[j * n + env_e] = rst ? 0.f : L.act[i];
+            if (P.track_ctrl) P.st.ctrl[j * n + env_e] = rst ? T->default_ctrl[j] : aclip[i];
         }
     }
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(QG_PO_THREADS) void qg_po_frame_kernel(KPoParams P,
             S.alias[env] = 1;                                              // :67 computed_orientation = data.qpos[3:7]
             S.nstep[env] = 0;
             // random_controls on the device: the new episode's command, drawn only now that both frames show the old one
-            if (sample_cmd) walk_sample_command(WP, WS, n, env, seed, env_index_base, episode[env]);
+            if (sample_cmd) walk_sample_command(WP, WS, n, env, seed, env_index_base, episode[env] - 1);
         }
     }
     __syncthreads();

@@ -1,0 +1,288 @@
+// qg_walk_dev.h -- per-env device functions of the walking task layer, shared by the stand-alone task kernels (qg_walk.hip)
+// and by the fused walking variant of the step kernel (qg_kernels.hip, qg_step_kernel_quad<.., WALK = true>): the control-signal
+// frequency / amplitude estimator (src/envs/math_utils.py:11-158), the command sampler (src/envs/control_inputs.py:74-115) and
+// the eleven reward terms of input_control_reward (src/envs/walking_quad.py:352-428).
+// Included from qg_kernels.hip after the counter-based random streams (uniform24s) it uses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QG_WALK_BLOCK 16      // samples per block summary of the estimator's ring buffer
+
+struct KWalkParams {
+    float dt;                    // timestep * frame_skip
+    int32_t settle_substeps;     // data.time < settling_time  <=>  nstep < settle_substeps (f64-accumulated clock)
+    int32_t window;              // estimator window size
+    float ema_alpha;
+    float control_cost_alpha;
+    float w[10];
+    float w_diff_ideal;
+    float body_height;
+    float joint_centers[12];
+    float amp_target[12];
+    float freq_target[12];
+    int32_t auto_reset;
+    // on-device command sampler (control_inputs.py:74-115); cmd_sample = 0: commands only change through qg_walk_set_commands
+    int32_t cmd_sample;
+    uint32_t cmd_fixed;
+    float cmd_min_speed, cmd_max_speed, cmd_theta, cmd_alpha, cmd_speed;
+};
+
+struct KWalkState {
+    // commands (control_inputs.py): local velocity xy, heading unit vector xy, global velocity xy   [2][n] each
+    float *vel, *head, *gvel;
+    float *ideal;            // [2][n]   ideal position (integrated commanded global velocity)
+    float *prev_ctrl;        // [12][n]  walking_quad.py:260-262
+    float *prev_ctrl_cost;   // [n]      set on the first step ever, never updated (:266-270)
+    uint8_t *has_ctrl_cost;  // [n]
+    float *prev_derive;      // [n]      previous_rewards_to_derive (:388-396)
+    uint8_t *has_derive;     // [n]      cleared by every reset (:109)
+    // estimator (math_utils.py): never reset between episodes (walking_quad.py:115)
+    int32_t *calls;          // [n]      update() calls so far: buffer index = calls % window, samples = min(calls, window)
+    float *sig;              // [window][12][n]
+    float *bmax, *bmin;      // [blocks][12][n]  max / min of each 16-sample block of the ring buffer
+    float *omax, *omin;      // [12][n]  max / min over the filled blocks other than the one being written (cache, see walk_estimator_update_n)
+    uint8_t *cross;          // [window][12][n]
+    int32_t *count;          // [12][n]  running number of derivative sign changes inside the window
+    float *prev;             // [12][n]
+    float *sign;             // [12][n]  -1 / 0 / +1
+    float *f_est, *a_est;    // [12][n]
+    float *eff_actions;      // [n][12]  the action actually applied (joint centres while settling)
+};
+
+
+// what the fused step kernel needs of the task layer, resident in device memory (uploaded by qg_walk_create and whenever the
+// command sampler changes)
+struct KWalkDev {
+    KWalkParams P;
+    KWalkState S;
+};
+
+// ---- estimator update of NCH channels of one env with data.ctrl (math_utils.py:53-131); t[c] = channel * n + env ------------
+// The amplitude is max - min over a sliding window of W samples.  The ring buffer carries per-block (16 samples) max / min
+// summaries, and -- new in round 2 -- the max / min over all OTHER filled blocks is cached while the write index stays inside one
+// block (it only changes when the index enters a new block, every 16th call), so a call touches the 16 samples of the current
+// block and eight scalars instead of 16 + 2 * 15 values behind a serial loop.  Written in three phases -- every load, then the
+// arithmetic, then every store -- so that the loads of all channels are in flight together: inside the fused step kernel a wave is
+// alone on its SIMD and a chain of dependent loads costs its full latency each time (measured: the loop form made the fused
+// walking step 42 us, slower than three launches).  max / min are exact, so the results are bit-identical to a full scan.
+#define QG_WALK_EMPTY_MAX (-3.0e38f)      // "no other block yet" (finite: the device pass is compiled with -ffinite-math-only)
+#define QG_WALK_EMPTY_MIN (3.0e38f)
+template <int NCH>
+__device__ __forceinline__ void walk_estimator_update_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], const float (&x)[NCH],
+                                                        int calls) {
+    const int W = P.window;
+    const int idx = calls % W;
+    const size_t stride = (size_t)12 * n;
+    if (calls == 0) {                                   // first call: remember the sample, estimates stay 0 (:66-72)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            S.prev[t[c]] = x[c];
+            S.sig[(size_t)idx * stride + t[c]] = x[c];
+            S.bmax[t[c]] = x[c];                        // block 0 holds exactly this sample
+            S.bmin[t[c]] = x[c];
+            S.omax[t[c]] = QG_WALK_EMPTY_MAX;
+            S.omin[t[c]] = QG_WALK_EMPTY_MIN;
+        }
+        return;
+    }
+    const int samples = min(calls + 1, W);              // :89-90
+    const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK, base = bidx * QG_WALK_BLOCK;
+    const int nblocks = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
+    const bool enter = j0 == 0;                         // the write index enters block bidx: the cache of the other blocks is rebuilt
+    // ---- phase 1: every load ----------------------------------------------------------------------------------------
+    float prev[NCH], psign[NCH], fe[NCH], ae[NCH], om[NCH], on[NCH], blk[NCH][QG_WALK_BLOCK];
+    int cnt[NCH], cr[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const size_t slot = (size_t)idx * stride + t[c];
+        prev[c] = S.prev[t[c]];
+        psign[c] = S.sign[t[c]];
+        cnt[c] = S.count[t[c]];
+        cr[c] = (int)S.cross[slot];                     // the slot holds 0 until the buffer wraps
+        fe[c] = S.f_est[t[c]];
+        ae[c] = S.a_est[t[c]];
+        om[c] = S.omax[t[c]];
+        on[c] = S.omin[t[c]];
+        const float *col = S.sig + t[c] + (size_t)base * stride;
+#pragma unroll
+        for (int j = 0; j < QG_WALK_BLOCK; ++j) {
+            const int slot_j = base + j;                // filled slots only (samples == W once the buffer has wrapped), not the one being written
+            blk[c][j] = (slot_j < samples && slot_j != idx) ? col[(size_t)j * stride] : x[c];
+        }
+    }
+    if (enter) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { om[c] = QG_WALK_EMPTY_MAX; on[c] = QG_WALK_EMPTY_MIN; }
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {                  // window <= 256 samples: at most 16 blocks (qg_walk_create checks)
+            if (b < nblocks && b != bidx && b * QG_WALK_BLOCK < samples) {      // blocks that hold at least one filled slot
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    om[c] = fmaxf(om[c], S.bmax[(size_t)b * stride + t[c]]);
+                    on[c] = fminf(on[c], S.bmin[(size_t)b * stride + t[c]]);
+                }
+            }
+        }
+    }
+    // ---- phase 2 / 3: arithmetic, then the stores ----------------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const size_t slot = (size_t)idx * stride + t[c];
+        float d = x[c] - prev[c];
+        float cur = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        int crossing = 0;
+        if (calls >= 2) {                               // a previous derivative sign exists (:78-86)
+            if (cur == 0.f) cur = psign[c];
+            crossing = (cur != psign[c]) ? 1 : 0;
+        }
+        const int count = cnt[c] - cr[c] + crossing;    // :94-96
+        const float dur = (float)samples * P.dt;        // :109
+        const float f_cur = (0.5f * (float)count) / dur;                        // :113-114
+        float mx = x[c], mn = x[c];
+#pragma unroll
+        for (int j = 0; j < QG_WALK_BLOCK; ++j) { mx = fmaxf(mx, blk[c][j]); mn = fminf(mn, blk[c][j]); }
+        const float amp = fmaxf(mx, om[c]) - fminf(mn, on[c]);                  // :121-126
+        S.cross[slot] = (uint8_t)crossing;
+        S.count[t[c]] = count;
+        S.sig[slot] = x[c];                             // :99
+        S.prev[t[c]] = x[c];                            // :105-106
+        S.sign[t[c]] = cur;
+        S.f_est[t[c]] = P.ema_alpha * fe[c] + (1.f - P.ema_alpha) * f_cur;      // :117
+        S.bmax[(size_t)bidx * stride + t[c]] = mx;      // summary of the current block, the new sample included
+        S.bmin[(size_t)bidx * stride + t[c]] = mn;
+        if (enter) { S.omax[t[c]] = om[c]; S.omin[t[c]] = on[c]; }
+        S.a_est[t[c]] = P.ema_alpha * ae[c] + (1.f - P.ema_alpha) * amp;        // :129
+    }
+}
+
+// ---- per-channel contributions to the reward sums; also moves previous_ctrl on (walking_quad.py:249-285) ------------------
+struct WalkSums { float cost, posture, amp, frq; };
+__device__ __forceinline__ void walk_channel_terms(const KWalkParams &P, const KWalkState &S, int n, int env, int j, float c /* data.ctrl, clipped */,
+                                                   WalkSums &a) {
+    const float inv_nu = 1.f / 12.f;
+    float dc = c - S.prev_ctrl[j * n + env];                         // control_cost (:254-270)
+    S.prev_ctrl[j * n + env] = c;
+    a.cost = fmaf(dc, dc, a.cost);
+    float pj = (c - P.joint_centers[j]) * inv_nu;                    // :249-253
+    a.posture = fmaf(pj, pj, a.posture);
+    float aj = (S.a_est[j * n + env] - P.amp_target[j]) * inv_nu;    // :279-285
+    a.amp = fmaf(aj, aj, a.amp);
+    float fj = (S.f_est[j * n + env] - P.freq_target[j]) * inv_nu;   // :272-277
+    a.frq = fmaf(fj, fj, a.frq);
+}
+
+// VelocityHeadingControls.sample (control_inputs.py:74-115) for one env: the command of the episode that has just begun.
+// `episode_key` is the counter of that episode in the env's reset streams -- the one its reset yaw used.
+__device__ __forceinline__ void walk_sample_command(const KWalkParams &P, const KWalkState &S, int n, int env, uint64_t seed,
+                                                    uint64_t env_index_base, int episode_key) {
+    const uint64_t g = env_index_base + (uint64_t)env, c = (uint64_t)episode_key;
+    const float pi = 3.14159265358979323846f;
+    float theta = P.cmd_theta, alpha = P.cmd_alpha, speed = P.cmd_speed;
+    if (!(P.cmd_fixed & 1u)) theta = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 0u) - 1.f);      // :97-100
+    if (!(P.cmd_fixed & 2u)) alpha = pi * (2.f * uniform24s(seed, g, c, QG_STREAM_COMMAND + 1u) - 1.f);      // :106-109
+    if (!(P.cmd_fixed & 4u)) speed = fmaf(P.cmd_max_speed - P.cmd_min_speed, uniform24s(seed, g, c, QG_STREAM_COMMAND + 2u), P.cmd_min_speed);   // :112-115
+    float st, ct, sa, ca;
+    sincosf(theta, &st, &ct);
+    sincosf(alpha, &sa, &ca);
+    const float vx = speed * ca, vy = speed * sa;          // set_velocity_speed_alpha (:45-51)
+    S.vel[env] = vx; S.vel[n + env] = vy;
+    S.head[env] = ct; S.head[n + env] = st;                // set_orientation (:29-36)
+    S.gvel[env] = ct * vx - st * vy;                       // :14-27
+    S.gvel[n + env] = st * vx + ct * vy;
+}
+
+// what the per-env part of the reward reads from the task state; loaded up front (in the fused kernel: in the prologue, so that
+// the latency hides behind the physics instead of sitting exposed in the epilogue of a wave that is alone on its SIMD)
+struct WalkEnvIn {
+    float cvx, cvy, hx, hy, gvx, gvy, ideal_x, ideal_y, first_cost, prev_derive;
+    int has_cost, has_derive;
+};
+__device__ __forceinline__ WalkEnvIn walk_env_load(const KWalkState &S, int n, int env) {
+    WalkEnvIn in;
+    in.cvx = S.vel[env]; in.cvy = S.vel[n + env];
+    in.hx = S.head[env]; in.hy = S.head[n + env];
+    in.gvx = S.gvel[env]; in.gvy = S.gvel[n + env];
+    in.ideal_x = S.ideal[env]; in.ideal_y = S.ideal[n + env];
+    in.first_cost = S.prev_ctrl_cost[env];
+    in.prev_derive = S.prev_derive[env];
+    in.has_cost = S.has_ctrl_cost[env];
+    in.has_derive = S.has_derive[env];
+    return in;
+}
+
+// ---- the per-env remainder of input_control_reward (walking_quad.py:352-428) once the four sums over the 12 channels are
+// known: the eleven weighted terms on the step's sensordata `s` (33 values, any address space), their total, the episode
+// bookkeeping of an env the physics has just auto-reset.  `in` = the task state as it stood BEFORE this step (walk_env_load);
+// the ideal position is integrated here (walking_quad.py:93,133: before the reward looks at it).
+__device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWalkState &S, int n, int env, const float *s, const WalkSums &sum,
+                                                const WalkEnvIn &in, bool finished, float *__restrict__ reward,
+                                                float *__restrict__ comps /* [n][11] or NULL */, int sample_here, uint64_t seed,
+                                                uint64_t env_index_base, int episode_key) {
+    const float px = s[18], py = s[19], pz = s[20];                  // body_pos
+    const float xax = s[24], xay = s[25];                            // body_xaxis
+    const float zaz = s[29];                                         // body_zaxis z
+    const float vx = s[30], vy = s[31];                              // body_vel (velocimeter, local)
+    const float cvx = in.cvx, cvy = in.cvy;
+    const float hx = in.hx, hy = in.hy;
+    const float ideal_x = fmaf(in.gvx, P.dt, in.ideal_x), ideal_y = fmaf(in.gvy, P.dt, in.ideal_y);    // :93,133
+    // control_cost (:254-270): EMA against the FIRST cost ever seen, which is never updated
+    float first_cost = in.first_cost;
+    if (!in.has_cost) {
+        first_cost = sum.cost;
+        S.prev_ctrl_cost[env] = sum.cost;
+        S.has_ctrl_cost[env] = 1;
+    }
+    const float control_cost = P.control_cost_alpha * first_cost + (1.f - P.control_cost_alpha) * sum.cost;
+    // progress terms on the local (velocimeter) velocity (:197-218).  unit() of a zero vector is NaN in the reference
+    // (math_utils.py:7-8) and that NaN reaches the direction term and the total.  The device pass is compiled with
+    // -ffinite-math-only, under which 0/0 is formally undefined, so the documented NaN is produced explicitly: the
+    // division is guarded and the quiet-NaN bit pattern is stored through integer selects below.
+    const float nv = __builtin_sqrtf(vx * vx + vy * vy), nc = __builtin_sqrtf(cvx * cvx + cvy * cvy);
+    const bool degenerate = (nv == 0.f) || (nc == 0.f);
+    const float dv = degenerate ? 1.f : nv, dc = degenerate ? 1.f : nc;
+    const float direction = (vx / dv) * (cvx / dc) + (vy / dv) * (cvy / dc);
+    const float dsp = nv - nc;
+    const float speed_cost = dsp * dsp;
+    const float heading = xax * hx + xay * hy;                       // :231-235
+    const float height = fabsf(pz - P.body_height);                  // :243-247
+    float v[11];
+    v[0] = P.w[0];
+    v[1] = P.w[1] * control_cost;
+    v[2] = P.w[2] * direction;
+    v[3] = P.w[3] * speed_cost;
+    v[4] = P.w[4] * (__expf(heading) - 1.f);                          // exp_dist, math_utils.py:4-5
+    v[5] = P.w[5] * (__expf(zaz) - 1.f);
+    v[6] = P.w[6] * (__expf(height) - 1.f);
+    v[7] = P.w[7] * __builtin_sqrtf(sum.posture);
+    v[8] = P.w[8] * __builtin_sqrtf(sum.amp);
+    v[9] = P.w[9] * __builtin_sqrtf(sum.frq);
+    // derived term (:383-396): d/dt of -20 * |pos_xy - ideal_xy|, zero on the first step after a reset
+    const float ex = px - ideal_x, ey = py - ideal_y;
+    const float derive = P.w_diff_ideal * __builtin_sqrtf(ex * ex + ey * ey);
+    const float prev = in.has_derive ? in.prev_derive : derive;
+    v[10] = (derive - prev) / P.dt;
+    S.prev_derive[env] = derive;
+    S.has_derive[env] = 1;
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) total += v[k];                       // :422 sum(values), in order
+    const unsigned qnan = 0x7FC00000u;
+    reinterpret_cast<unsigned *>(reward)[env] = degenerate ? qnan : __builtin_bit_cast(unsigned, total);
+    if (comps) {
+        unsigned *cu = reinterpret_cast<unsigned *>(comps) + (size_t)env * 11;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) cu[k] = (k == 2 && degenerate) ? qnan : __builtin_bit_cast(unsigned, v[k]);
+    }
+    S.calls[env] += 1;                                                // the estimator update of this step is complete
+    // episode bookkeeping of envs the physics has just auto-reset (walking_quad.py:96-126)
+    const bool restart = P.auto_reset && finished;
+    S.ideal[env] = restart ? 0.f : ideal_x;
+    S.ideal[n + env] = restart ? 0.f : ideal_y;
+    if (restart) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) S.prev_ctrl[j * n + env] = P.joint_centers[j];
+        S.has_derive[env] = 0;
+        if (sample_here) walk_sample_command(P, S, n, env, seed, env_index_base, episode_key);     // walking_quad.py:121-122
+    }
+}

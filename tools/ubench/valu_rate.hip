@@ -3,6 +3,7 @@
 // build: hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize -o valu_rate valu_rate.hip ; run: ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f2 __attribute__((ext_vector_type(2)));
 #define ITERS 2048
 #define REP 8      // 8 x 8 = 64 fma per loop iteration
@@ -48,6 +49,16 @@ template <int MODE> __global__ __launch_bounds__(64) void k(float *out, float a,
             for (int r = 0; r < REP; r++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) x[i] = __builtin_fmaf(x[i], x[(i + 1) & 7], x[(i + 2) & 7]);
+        } else if (MODE == 8) {   // dependent chain, VGPR sources only (no SGPR / constant-bus operand): x0 = fma(x0, x1, x2)
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[0] = __builtin_fmaf(x[0], x[1], x[2]);
+        } else if (MODE == 9) {   // two interleaved dependent chains, VGPR sources only (ILP 2)
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) { x[0] = __builtin_fmaf(x[0], x[2], x[3]); x[1] = __builtin_fmaf(x[1], x[2], x[3]); }
         } else {                  // 8 independent packed chains
 #pragma unroll
             for (int r = 0; r < REP; r++)
@@ -79,6 +90,13 @@ template <int MODE> void run(const char *name, int waves_per_simd, float *d) {
 }
 int main() {
     float *d; hipMalloc(&d, 8192 * 64 * 4);
+    for (int w = 1; w <= 8; w++) {      // round 2: does occupancy hide dependent-issue stalls when no SGPR operand is involved?
+        if (w == 5 || w == 7) continue;
+        run<8>("v_fma_f32 dependent, VGPR only", w, d);
+        run<9>("v_fma_f32 2 chains, VGPR only", w, d);
+        run<7>("v_fma_f32 3 VGPRs 8 indep", w, d);
+    }
+    if (getenv("QG_UBENCH_ALL"))
     for (int w = 1; w <= 4; w *= 2) {
         run<0>("v_fma_f32 dependent", w, d);
         run<1>("v_fma_f32 8 independent", w, d);
