@@ -242,12 +242,8 @@ static int effective_mapping(const qg_sim *s) {
 // `walk` != NULL: the fused walking launch (one-leg-per-lane kernel with the task layer folded in); walk_comps / walk_sample go
 // with it
 static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_done, float *d_comps,
-                       float *d_packed, hipStream_t stream, const KWalkDev *walk = nullptr, float *walk_comps = nullptr,
-                       int walk_sample = 0) {
+                       float *d_packed, hipStream_t stream, const KWalkLaunch *walk = nullptr) {
     KStepArgs P;
-    P.walk = walk;
-    P.walk_comps = walk_comps;
-    P.walk_sample = walk_sample;
     P.st = s->st;
     P.n = s->n;
     P.track_ctrl = s->track_ctrl;
@@ -264,9 +260,9 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
-        if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-        else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-        else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+        if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
+        else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
+        else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         hipLaunchKernelGGL(qg_step_kernel_pair, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
@@ -275,14 +271,14 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
         if (s->baked) {
             const int wpe = s->quad_wpe ? s->quad_wpe : (one_wave ? 1 : 2);
-            if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
-            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+            if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
         } else {
             // tables in LDS: the 256-register cap spills 888 B per lane and measured 2x slower at every grid size (363 vs 741 us
             // at 262 144 envs), so any other robot runs the one-wave-per-SIMD form throughout
-            hipLaunchKernelGGL((qg_step_kernel_quad<1, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
+            hipLaunchKernelGGL((qg_step_kernel_quad<1, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
         }
     } else if (s->baked)
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
@@ -540,21 +536,13 @@ struct qg_walk {
     KWalkState st;
     float *d_obs, *d_reward, *d_comps, *d_actions, *d_tmp;
     uint8_t *d_done;
-    KWalkDev *d_dev;          // {kp, st} in device memory for the fused walking launch; refreshed by walk_upload()
 };
 
-// the fused launch reads the task parameters / state pointers from device memory: keep that copy in step with w->kp / w->st
-static int walk_upload(qg_walk *w) {
-    KWalkDev h;
-    h.P = w->kp;
-    h.S = w->st;
-    HIP_TRY(hipMemcpy(w->d_dev, &h, sizeof h, hipMemcpyHostToDevice), QG_ERR_DEVICE);
-    return QG_OK;
-}
-
-// The walking env-step is ONE launch with the one-leg-per-lane mapping (AUTO takes it at every batch size: the three-launch
-// form of the other mappings costs more than their kernels gain); an explicit LANE / PAIR request keeps the three launches.
-static bool walk_fused(const qg_sim *s) { return s->mapping == QG_MAP_AUTO || s->mapping == QG_MAP_QUAD; }
+// The walking env-step is ONE launch wherever the one-leg-per-lane kernel is what runs (AUTO: up to 16 384 envs and between 32 769
+// and 57 343; an explicit QUAD: always): 23.3 us against 33.0 us for estimator -> physics -> reward at 4096 envs.  Where AUTO takes
+// the two-legs-per-lane kernel (16 385 .. 32 768 envs, >= 57 344) the three launches around it stay ahead (46.6 us against 52.5 us
+// fused at 32 768 envs); LANE / PAIR requests keep the three launches too.
+static bool walk_fused(const qg_sim *s) { return effective_mapping(s) == QG_MAP_QUAD; }
 
 extern "C" int qg_walk_default_params(qg_walk_params *p) {
     if (!p) return fail(QG_ERR_ARG, "qg_walk_default_params: null output");
@@ -590,7 +578,7 @@ extern "C" int qg_walk_destroy(qg_walk *w) {
     }
     void *ptrs[] = {w->st.vel, w->st.head, w->st.gvel, w->st.ideal, w->st.prev_ctrl, w->st.prev_ctrl_cost, w->st.has_ctrl_cost,
                     w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.omax, w->st.omin, w->st.cross, w->st.count, w->st.prev, w->st.sign,
-                    w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done, w->d_dev};
+                    w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete w;
@@ -616,9 +604,9 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     int64_t settle = params->settling_time > 0 ? qg_time_limit_substeps_impl(s->model.timestep, params->settling_time) : 0;
     k.settle_substeps = (int32_t)(settle > INT32_MAX ? INT32_MAX : settle);
     k.window = (int32_t)std::ceil(2.0 / (params->min_freq * dt));   // math_utils.py:26-28
-    if (k.window < 1 || k.window > 16 * QG_WALK_BLOCK) {
+    if (k.window < 1 || k.window > QG_WALK_MAXBLOCKS * QG_WALK_BLOCK) {
         delete w;
-        return fail(QG_ERR_ARG, "qg_walk_create: estimator window %d outside 1..%d samples (min_freq * timestep * frame_skip too small)", k.window, 16 * QG_WALK_BLOCK);
+        return fail(QG_ERR_ARG, "qg_walk_create: estimator window %d outside 1..%d samples (min_freq * timestep * frame_skip too small)", k.window, QG_WALK_MAXBLOCKS * QG_WALK_BLOCK);
     }
     k.ema_alpha = (float)params->ema_alpha;
     k.control_cost_alpha = (float)params->control_cost_alpha;
@@ -644,19 +632,17 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     WALLOC(w->st.vel, 2 * n * 4); WALLOC(w->st.head, 2 * n * 4); WALLOC(w->st.gvel, 2 * n * 4); WALLOC(w->st.ideal, 2 * n * 4);
     WALLOC(w->st.prev_ctrl, 12 * n * 4); WALLOC(w->st.prev_ctrl_cost, n * 4); WALLOC(w->st.has_ctrl_cost, n);
     WALLOC(w->st.prev_derive, n * 4); WALLOC(w->st.has_derive, n); WALLOC(w->st.calls, n * 4);
-    WALLOC(w->st.sig, W * 12 * n * 4); WALLOC(w->st.cross, W * 12 * n);
-    {
-        size_t nb = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
-        WALLOC(w->st.bmax, nb * 12 * n * 4); WALLOC(w->st.bmin, nb * 12 * n * 4);
+    {   // the ring in whole blocks and all 16 summary slots, whatever the window: the estimator's loads are unconditional
+        const size_t nb = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK, Wp = nb * QG_WALK_BLOCK;
+        WALLOC(w->st.sig, Wp * 12 * n * 4); WALLOC(w->st.cross, Wp * 12 * n);
+        WALLOC(w->st.bmax, (size_t)QG_WALK_MAXBLOCKS * 12 * n * 4); WALLOC(w->st.bmin, (size_t)QG_WALK_MAXBLOCKS * 12 * n * 4);
     }
     WALLOC(w->st.omax, 12 * n * 4); WALLOC(w->st.omin, 12 * n * 4); WALLOC(w->st.count, 12 * n * 4);
     WALLOC(w->st.prev, 12 * n * 4); WALLOC(w->st.sign, 12 * n * 4); WALLOC(w->st.f_est, 12 * n * 4); WALLOC(w->st.a_est, 12 * n * 4);
     WALLOC(w->st.eff_actions, 12 * n * 4);
     WALLOC(w->d_obs, n * QG_NSENSOR * 4); WALLOC(w->d_reward, n * 4); WALLOC(w->d_comps, n * QG_NWALKREWARD * 4);
     WALLOC(w->d_actions, n * 12 * 4); WALLOC(w->d_tmp, n * 12 * 4); WALLOC(w->d_done, n);
-    WALLOC(w->d_dev, sizeof(KWalkDev));
 #undef WALLOC
-    { int rc = walk_upload(w); if (rc != QG_OK) { qg_walk_destroy(w); return rc; } }
     // the reference's termination set for this env: flip or time limit (walking_quad.py:162-166); data.ctrl feeds the estimator
     w->saved_use_flip = s->task.use_flip;
     w->saved_track_ctrl = s->track_ctrl;
@@ -720,7 +706,7 @@ extern "C" int qg_walk_set_command_sampler(qg_walk *w, const qg_command_sampler 
     KWalkParams &k = w->kp;
     HIP_TRY(hipSetDevice(w->sim->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps reading the old parameters may be in flight
-    if (!c) { k.cmd_sample = 0; return walk_upload(w); }
+    if (!c) { k.cmd_sample = 0; return QG_OK; }
     if (c->fixed & ~7u) return fail(QG_ERR_ARG, "qg_walk_set_command_sampler: unknown bits in `fixed`");
     if (!(c->fixed & QG_CMD_FIXED_SPEED) && !(std::fabs(c->min_speed) < 1e30 && std::fabs(c->max_speed) < 1e30))
         return fail(QG_ERR_ARG, "qg_walk_set_command_sampler: min_speed / max_speed must be finite");
@@ -731,7 +717,7 @@ extern "C" int qg_walk_set_command_sampler(qg_walk *w, const qg_command_sampler 
     k.cmd_alpha = (float)c->fixed_velocity_angle;
     k.cmd_speed = (float)c->fixed_speed;
     k.cmd_sample = 1;
-    return walk_upload(w);
+    return QG_OK;
 }
 
 extern "C" int qg_walk_get_commands(qg_walk *w, float *velocity_xy, float *heading_xy) {
@@ -777,8 +763,14 @@ static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *r
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     hipStream_t st = (hipStream_t)stream;
-    if (walk_fused(s))
-        return launch_step(s, actions, obs, reward, done, nullptr, nullptr, st, w->d_dev, components, (w->kp.cmd_sample && !po_follows) ? 1 : 0);
+    if (walk_fused(s)) {
+        KWalkLaunch wl;
+        wl.P = w->kp;
+        wl.S = w->st;
+        wl.comps = components;
+        wl.sample = (w->kp.cmd_sample && !po_follows) ? 1 : 0;
+        return launch_step(s, actions, obs, reward, done, nullptr, nullptr, st, &wl);
+    }
     int threads = 256;
     int total = 12 * s->n;
     hipLaunchKernelGGL(qg_walk_pre_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, w->kp, w->st, s->n, actions,

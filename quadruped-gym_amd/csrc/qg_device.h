@@ -75,8 +75,4 @@ struct KStepArgs {
     float *packed;            // [n][obs_dim+2] or NULL
     uint64_t seed;            // reset stream
     uint64_t env_index_base;
-    // fused walking task layer (qg_step_kernel_quad<.., WALK = true> only; NULL / 0 otherwise)
-    const struct KWalkDev *walk;   // task parameters and per-env task state, device memory
-    float *walk_comps;             // [n][11] or NULL
-    int32_t walk_sample;           // redraw the command of the envs this step auto-resets
 };

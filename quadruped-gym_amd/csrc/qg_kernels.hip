@@ -1054,7 +1054,8 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 // need data.ctrl of the PREVIOUS step, which is still in place there), ideal-position integration, the eleven reward terms and
 // the episode bookkeeping in the epilogue on the sensor row the wave has just staged in LDS.
 template <int WPE, bool BAKED, bool WALK = false>
-__global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P) {
+__global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
+                                                                     const typename WalkArgT<WALK>::type WK) {
     __shared__ float tile[QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
     const int lane = threadIdx.x;
@@ -1087,26 +1088,30 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
     int calls = 0;
     WalkEnvIn win = {};
     if constexpr (WALK) {
-        settle = nstep0 < P.walk->P.settle_substeps;                // data.time < settling_time (walking_quad.py:142-143)
-        calls = P.walk->S.calls[env];
+        settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
+        calls = WK.S.calls[env];
     }
+    // WALK: every load of the task layer goes out here, among the state loads, and every store of its prologue part comes after the
+    // last load of the kernel's prologue (a load behind a store would wait for that store: vmcnt counts in order)
+    const int tt[3] = {(3 * k + 0) * n + env, (3 * k + 1) * n + env, (3 * k + 2) * n + env};
+    float xx[3] = {0.f, 0.f, 0.f}, wprev[3] = {0.f, 0.f, 0.f}, wf[3] = {0.f, 0.f, 0.f}, wa[3] = {0.f, 0.f, 0.f}, a_eff[3] = {0.f, 0.f, 0.f};
+    WalkEstIn<3> west;
     if constexpr (WALK) {
-        // the estimator takes data.ctrl of the PREVIOUS step (walking_quad.py:136), still in place here; its loads go out together
-        // with the state loads around them
-        const KWalkDev &W = *P.walk;
-        const int tt[3] = {(3 * k + 0) * n + env, (3 * k + 1) * n + env, (3 * k + 2) * n + env};
-        const float xx[3] = {P.st.ctrl[tt[0]], P.st.ctrl[tt[1]], P.st.ctrl[tt[2]]};
-        if (live) walk_estimator_update_n<3>(W.P, W.S, n, tt, xx, calls);
-        if (live && k == 0) win = walk_env_load(W.S, n, env);       // what the reward epilogue reads: fetched now, behind the physics
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            xx[i] = P.st.ctrl[tt[i]];                 // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+            wprev[i] = WK.S.prev_ctrl[tt[i]];         // previous_ctrl of the control cost (:260-262)
+        }
+        walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
+        if (k == 0) win = walk_env_load(WK.S, n, env);  // what the reward epilogue reads: fetched now, behind the physics
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = 3 * k + i;
         float a_in = P.actions[(size_t)env * 12 + j];
         if constexpr (WALK) {
-            const KWalkDev &W = *P.walk;
-            if (settle) a_in = W.P.joint_centers[j];                 // the joint centres while the robot settles
-            if (live) W.S.eff_actions[(size_t)env * 12 + j] = a_in;  // the action actually applied (read again by the PO pack)
+            if (settle) a_in = WK.P.joint_centers[j];                // the joint centres while the robot settles
+            a_eff[i] = a_in;
         }
         float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
         aclip0[i] = a;
@@ -1114,6 +1119,18 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         L.q[i] = P.st.qpos[(7 + j) * n + env];
         L.qd[i] = P.st.qvel[(6 + j) * n + env];
         L.act[i] = P.st.act[j * n + env];
+    }
+    if constexpr (WALK) {
+        // every state value is in its register before the first store of the task layer is issued: the waits for those loads
+        // would otherwise sit behind the stores (vmcnt is in order) right in front of the substep loop
+        asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
+                     "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(L.q[0]), "v"(L.q[1]), "v"(L.q[2]), "v"(L.qd[0]), "v"(L.qd[1]), "v"(L.qd[2]),
+                     "v"(L.act[0]), "v"(L.act[1]), "v"(L.act[2]), "v"(L.u[0]), "v"(L.u[1]), "v"(L.u[2]) : "memory");
+        if (live) {
+            walk_estimator_finish_n<3>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+#pragma unroll
+            for (int i = 0; i < 3; ++i) WK.S.eff_actions[(size_t)env * 12 + 3 * k + i] = a_eff[i];   // the action actually applied (the PO pack reads it)
+        }
     }
 
     // the sensor values of the step go straight into this env's row of the output tile (full 33-value layout; the
@@ -1183,7 +1200,8 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         nstep = P.st.nstep[env_e] + fs;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float *asrc = WALK ? P.walk->S.eff_actions : P.actions;
+            const float *asrc = P.actions;
+            if constexpr (WALK) asrc = WK.S.eff_actions;
             aclip[i] = fminf(fmaxf(asrc[(size_t)env_e * 12 + 3 * k_e + i], -1.f), 1.f);     // quadruped.py:160
         }
     }
@@ -1231,16 +1249,15 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         P.done[env_e] = done ? 1 : 0;
     }
     if constexpr (WALK) {
-        const KWalkDev &W = *P.walk;
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
         if (live) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) walk_channel_terms(W.P, W.S, n, env_e, 3 * k_e + i, aclip[i], sum);
+            for (int i = 0; i < 3; ++i) walk_channel_terms(WK.P, WK.S, n, env_e, 3 * k_e + i, aclip[i], wprev[i], wf[i], wa[i], sum);
         }
         sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
         if (lead) {
             // the env's episode counter has not been advanced yet: it is the key of the episode that begins if this one ends
-            walk_reward_env(W.P, W.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, P.walk_comps, P.walk_sample, P.seed,
+            walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed,
                             P.env_index_base, P.st.episode[env_e]);
         }
     }

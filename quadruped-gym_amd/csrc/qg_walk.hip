@@ -38,7 +38,11 @@ __global__ void qg_walk_pre_kernel(KWalkParams P, KWalkState S, int n, const flo
     S.eff_actions[(size_t)env * 12 + ch] = settle ? P.joint_centers[ch] : actions[(size_t)env * 12 + ch];
     const int tt[1] = {t};
     const float xx[1] = {data_ctrl[t]};
-    walk_estimator_update_n<1>(P, S, n, tt, xx, S.calls[env]);            // math_utils.py:53-131 with data.ctrl (:136)
+    const int calls = S.calls[env];
+    WalkEstIn<1> in;
+    float f_new[1], a_new[1];
+    walk_estimator_load_n<1>(P, S, n, tt, calls, in);                     // math_utils.py:53-131 with data.ctrl (:136)
+    walk_estimator_finish_n<1>(P, S, n, tt, xx, calls, in, f_new, a_new);
 }
 
 // one thread per env.  `sample_here`: redraw the command of the envs the step has auto-reset (random_controls on the device);
@@ -53,7 +57,7 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
     for (int j = 0; j < 12; ++j) {
         float c = S.eff_actions[(size_t)env * 12 + j];               // data.ctrl after the step
         c = fminf(fmaxf(c, -1.f), 1.f);                              // quadruped.py:160
-        walk_channel_terms(P, S, n, env, j, c, sum);
+        walk_channel_terms(P, S, n, env, j, c, S.prev_ctrl[j * n + env], S.f_est[j * n + env], S.a_est[j * n + env], sum);
     }
     // the physics reset has already advanced the env's episode counter: the key of the episode that begins is episode - 1
     const WalkEnvIn in = walk_env_load(S, n, env);

@@ -51,12 +51,18 @@ struct KWalkState {
 };
 
 
-// what the fused step kernel needs of the task layer, resident in device memory (uploaded by qg_walk_create and whenever the
-// command sampler changes)
-struct KWalkDev {
+// what the fused walking variant of the step kernel takes as an extra by-value kernel argument.  By value on purpose: the kernarg
+// segment is constant memory to the compiler, so the two dozen state pointers stay in scalar registers; behind a device-memory
+// pointer every one of them was re-loaded (vector load + full vmcnt wait) after each store that might alias it.
+struct KWalkLaunch {
     KWalkParams P;
     KWalkState S;
+    float *comps;            // [n][11] or NULL
+    int32_t sample;          // redraw the command of the envs this step auto-resets
 };
+struct KWalkNone {};
+template <bool WALK> struct WalkArgT { typedef KWalkNone type; };
+template <> struct WalkArgT<true> { typedef KWalkLaunch type; };
 
 // ---- estimator update of NCH channels of one env with data.ctrl (math_utils.py:53-131); t[c] = channel * n + env ------------
 // The amplitude is max - min over a sliding window of W samples.  The ring buffer carries per-block (16 samples) max / min
@@ -66,11 +72,61 @@ struct KWalkDev {
 // arithmetic, then every store -- so that the loads of all channels are in flight together: inside the fused step kernel a wave is
 // alone on its SIMD and a chain of dependent loads costs its full latency each time (measured: the loop form made the fused
 // walking step 42 us, slower than three launches).  max / min are exact, so the results are bit-identical to a full scan.
+#define QG_WALK_MAXBLOCKS 16              // the ring buffer and its summaries are allocated for 16 blocks (window <= 256 samples)
 #define QG_WALK_EMPTY_MAX (-3.0e38f)      // "no other block yet" (finite: the device pass is compiled with -ffinite-math-only)
 #define QG_WALK_EMPTY_MIN (3.0e38f)
+template <int NCH> struct WalkEstIn {
+    float prev[NCH], psign[NCH], fe[NCH], ae[NCH], om[NCH], on[NCH], blk[NCH][QG_WALK_BLOCK];
+    int cnt[NCH], cr[NCH];
+};
+// phase 1: every load of the update (nothing is stored): call it among the caller's other loads
 template <int NCH>
-__device__ __forceinline__ void walk_estimator_update_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], const float (&x)[NCH],
-                                                        int calls) {
+__device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], int calls, WalkEstIn<NCH> &in) {
+    const int W = P.window;
+    const int idx = calls % W;
+    const size_t stride = (size_t)12 * n;
+    const int samples = min(calls + 1, W);              // :89-90
+    const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK, base = bidx * QG_WALK_BLOCK;
+    const int nblocks = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const size_t slot = (size_t)idx * stride + t[c];
+        in.prev[c] = S.prev[t[c]];
+        in.psign[c] = S.sign[t[c]];
+        in.cnt[c] = S.count[t[c]];
+        in.cr[c] = (int)S.cross[slot];                  // the slot holds 0 until the buffer wraps
+        in.fe[c] = S.f_est[t[c]];
+        in.ae[c] = S.a_est[t[c]];
+        in.om[c] = S.omax[t[c]];
+        in.on[c] = S.omin[t[c]];
+        const float *col = S.sig + t[c] + (size_t)base * stride;
+#pragma unroll
+        for (int j = 0; j < QG_WALK_BLOCK; ++j) in.blk[c][j] = col[(size_t)j * stride];   // unconditional: the ring is allocated in whole blocks
+    }
+    if (calls > 0 && j0 == 0) {                         // the write index enters block bidx: the cache of the other blocks is rebuilt
+        float hi[NCH][QG_WALK_MAXBLOCKS], lo[NCH][QG_WALK_MAXBLOCKS];
+#pragma unroll
+        for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // every summary slot exists (16 blocks are allocated whatever the window): plain loads ...
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { hi[c][b] = S.bmax[(size_t)b * stride + t[c]]; lo[c][b] = S.bmin[(size_t)b * stride + t[c]]; }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { in.om[c] = QG_WALK_EMPTY_MAX; in.on[c] = QG_WALK_EMPTY_MIN; }
+#pragma unroll
+        for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // ... then selects
+            const bool use = b < nblocks && b != bidx && b * QG_WALK_BLOCK < samples;      // blocks that hold at least one filled slot
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                in.om[c] = fmaxf(in.om[c], use ? hi[c][b] : QG_WALK_EMPTY_MAX);
+                in.on[c] = fminf(in.on[c], use ? lo[c][b] : QG_WALK_EMPTY_MIN);
+            }
+        }
+    }
+}
+// phases 2 and 3: the arithmetic and every store; returns the new estimates (what the reward of this step reads)
+template <int NCH>
+__device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], const float (&x)[NCH],
+                                                        int calls, const WalkEstIn<NCH> &in, float (&f_new)[NCH], float (&a_new)[NCH]) {
     const int W = P.window;
     const int idx = calls % W;
     const size_t stride = (size_t)12 * n;
@@ -83,92 +139,62 @@ __device__ __forceinline__ void walk_estimator_update_n(const KWalkParams &P, co
             S.bmin[t[c]] = x[c];
             S.omax[t[c]] = QG_WALK_EMPTY_MAX;
             S.omin[t[c]] = QG_WALK_EMPTY_MIN;
+            f_new[c] = in.fe[c];
+            a_new[c] = in.ae[c];
         }
         return;
     }
     const int samples = min(calls + 1, W);              // :89-90
     const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK, base = bidx * QG_WALK_BLOCK;
-    const int nblocks = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
-    const bool enter = j0 == 0;                         // the write index enters block bidx: the cache of the other blocks is rebuilt
-    // ---- phase 1: every load ----------------------------------------------------------------------------------------
-    float prev[NCH], psign[NCH], fe[NCH], ae[NCH], om[NCH], on[NCH], blk[NCH][QG_WALK_BLOCK];
-    int cnt[NCH], cr[NCH];
+    const bool enter = j0 == 0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const size_t slot = (size_t)idx * stride + t[c];
-        prev[c] = S.prev[t[c]];
-        psign[c] = S.sign[t[c]];
-        cnt[c] = S.count[t[c]];
-        cr[c] = (int)S.cross[slot];                     // the slot holds 0 until the buffer wraps
-        fe[c] = S.f_est[t[c]];
-        ae[c] = S.a_est[t[c]];
-        om[c] = S.omax[t[c]];
-        on[c] = S.omin[t[c]];
-        const float *col = S.sig + t[c] + (size_t)base * stride;
-#pragma unroll
-        for (int j = 0; j < QG_WALK_BLOCK; ++j) {
-            const int slot_j = base + j;                // filled slots only (samples == W once the buffer has wrapped), not the one being written
-            blk[c][j] = (slot_j < samples && slot_j != idx) ? col[(size_t)j * stride] : x[c];
-        }
-    }
-    if (enter) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) { om[c] = QG_WALK_EMPTY_MAX; on[c] = QG_WALK_EMPTY_MIN; }
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {                  // window <= 256 samples: at most 16 blocks (qg_walk_create checks)
-            if (b < nblocks && b != bidx && b * QG_WALK_BLOCK < samples) {      // blocks that hold at least one filled slot
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    om[c] = fmaxf(om[c], S.bmax[(size_t)b * stride + t[c]]);
-                    on[c] = fminf(on[c], S.bmin[(size_t)b * stride + t[c]]);
-                }
-            }
-        }
-    }
-    // ---- phase 2 / 3: arithmetic, then the stores ----------------------------------------------------------------------
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const size_t slot = (size_t)idx * stride + t[c];
-        float d = x[c] - prev[c];
+        float d = x[c] - in.prev[c];
         float cur = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-        int crossing = 0;
-        if (calls >= 2) {                               // a previous derivative sign exists (:78-86)
-            if (cur == 0.f) cur = psign[c];
-            crossing = (cur != psign[c]) ? 1 : 0;
-        }
-        const int count = cnt[c] - cr[c] + crossing;    // :94-96
+        const bool have_sign = calls >= 2;              // a previous derivative sign exists (:78-86)
+        cur = (have_sign && cur == 0.f) ? in.psign[c] : cur;
+        const int crossing = (have_sign && cur != in.psign[c]) ? 1 : 0;
+        const int count = in.cnt[c] - in.cr[c] + crossing;                      // :94-96
         const float dur = (float)samples * P.dt;        // :109
         const float f_cur = (0.5f * (float)count) / dur;                        // :113-114
         float mx = x[c], mn = x[c];
 #pragma unroll
-        for (int j = 0; j < QG_WALK_BLOCK; ++j) { mx = fmaxf(mx, blk[c][j]); mn = fminf(mn, blk[c][j]); }
-        const float amp = fmaxf(mx, om[c]) - fminf(mn, on[c]);                  // :121-126
+        for (int j = 0; j < QG_WALK_BLOCK; ++j) {
+            const int slot_j = base + j;                // filled slots only (samples == W once the buffer has wrapped), not the one being written
+            const float v = (slot_j < samples && slot_j != idx) ? in.blk[c][j] : x[c];
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+        }
+        const float amp = fmaxf(mx, in.om[c]) - fminf(mn, in.on[c]);            // :121-126
+        f_new[c] = P.ema_alpha * in.fe[c] + (1.f - P.ema_alpha) * f_cur;        // :117
+        a_new[c] = P.ema_alpha * in.ae[c] + (1.f - P.ema_alpha) * amp;          // :129
         S.cross[slot] = (uint8_t)crossing;
         S.count[t[c]] = count;
         S.sig[slot] = x[c];                             // :99
         S.prev[t[c]] = x[c];                            // :105-106
         S.sign[t[c]] = cur;
-        S.f_est[t[c]] = P.ema_alpha * fe[c] + (1.f - P.ema_alpha) * f_cur;      // :117
+        S.f_est[t[c]] = f_new[c];
         S.bmax[(size_t)bidx * stride + t[c]] = mx;      // summary of the current block, the new sample included
         S.bmin[(size_t)bidx * stride + t[c]] = mn;
-        if (enter) { S.omax[t[c]] = om[c]; S.omin[t[c]] = on[c]; }
-        S.a_est[t[c]] = P.ema_alpha * ae[c] + (1.f - P.ema_alpha) * amp;        // :129
+        if (enter) { S.omax[t[c]] = in.om[c]; S.omin[t[c]] = in.on[c]; }
+        S.a_est[t[c]] = a_new[c];
     }
 }
 
 // ---- per-channel contributions to the reward sums; also moves previous_ctrl on (walking_quad.py:249-285) ------------------
 struct WalkSums { float cost, posture, amp, frq; };
 __device__ __forceinline__ void walk_channel_terms(const KWalkParams &P, const KWalkState &S, int n, int env, int j, float c /* data.ctrl, clipped */,
-                                                   WalkSums &a) {
+                                                   float prev_ctrl, float f_est, float a_est, WalkSums &a) {
     const float inv_nu = 1.f / 12.f;
-    float dc = c - S.prev_ctrl[j * n + env];                         // control_cost (:254-270)
+    float dc = c - prev_ctrl;                                        // control_cost (:254-270)
     S.prev_ctrl[j * n + env] = c;
     a.cost = fmaf(dc, dc, a.cost);
     float pj = (c - P.joint_centers[j]) * inv_nu;                    // :249-253
     a.posture = fmaf(pj, pj, a.posture);
-    float aj = (S.a_est[j * n + env] - P.amp_target[j]) * inv_nu;    // :279-285
+    float aj = (a_est - P.amp_target[j]) * inv_nu;                   // :279-285
     a.amp = fmaf(aj, aj, a.amp);
-    float fj = (S.f_est[j * n + env] - P.freq_target[j]) * inv_nu;   // :272-277
+    float fj = (f_est - P.freq_target[j]) * inv_nu;                  // :272-277
     a.frq = fmaf(fj, fj, a.frq);
 }
 
