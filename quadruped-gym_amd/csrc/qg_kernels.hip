@@ -217,6 +217,19 @@ template <class T> DEV void sincos_f(T x, T &s, T &c) {
     }
 }
 
+// sin / cos of a hinge rotation advanced by the substep's own increment d = h * qd_new (|d| < 0.05 rad: the 5th-order series is
+// exact to f32 rounding) instead of re-evaluated from the angle: 10 instructions per hinge and substep against 25.  The env-step
+// starts from the polynomial values, so the rounding of at most frame_skip products accumulates (measured inside the stated
+// tolerances at frame_skip 4 and 20).
+template <class T> DEV void hinge_advance(T d, T &sn, T &cs) {
+    T d2 = d * d;
+    T sd = d * fma_(d2, fma_(d2, T(1.f / 120.f), T(-1.f / 6.f)), T(1.f));
+    T cd = fma_(d2, fma_(d2, T(1.f / 24.f), T(-0.5f)), T(1.f));
+    T s1 = fma_(sn, cd, cs * sd);
+    cs = fma_(cs, cd, -(sn * sd));
+    sn = s1;
+}
+
 // Divergence guard.  The engine being replaced checks positions / velocities / accelerations every step and resets
 // a simulation that produced NaN / Inf or huge values (mj_checkPos / mj_checkVel / mj_checkAcc); here such an env is
 // reported as done (and reset when auto_reset is on).  The device pass is compiled with -ffinite-math-only, so the
@@ -392,9 +405,11 @@ DEV void frame_body(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic
 // COMPACT: keep (rigid inertia, contact-damping numbers) per link -- 14 live values instead of a 21-value 6x6 -- and assemble the
 // 6x6 forms in the backward pass straight into the composite.  Same arithmetic per term, different summation order; used by the
 // register-capped (3 and 4 waves per SIMD) instantiations of the one-leg-per-lane kernel.
+// sc: sin / cos of the three hinge rotations carried by the caller (advanced by each substep's small rotation, see hinge_advance),
+// or NULL: evaluate the polynomials here.
 template <class T, bool BAKED, bool QUAD, bool CULL_FEMUR = false, bool COMPACT = false>
 DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3], const T act[3], const BaseCtx &bc, float zbase_f,
-                  float h, Sym6T<T> &Ic, SVT<T> &fc, SVT<T> F[3], T Hd[3], T &H01, T &H02, T &H12, T bj[3]) {
+                  float h, Sym6T<T> &Ic, SVT<T> &fc, SVT<T> F[3], T Hd[3], T &H01, T &H02, T &H12, T bj[3], const T *sc = nullptr) {
     const T zero = T(0.f);
     V3T<T> pp = v3<T>(zero, zero, zero);
     const V3T<T> nb = splat3<T>(bc.n);
@@ -410,9 +425,9 @@ DEV void leg_pass(const KModel &C, int k, FrT<T> Ep, const T q[3], const T qd[3]
     for (int i = 0; i < 3; ++i) {
         const KLink &L = link_of<BAKED>(C, k, i);
         const KLink &Lm = QUAD ? C.link[i] : ((i == 0) ? C.link[3 * k] : L);   // the fema's mounting transform differs per leg
-        T th = q[i] - T(L.ref);      // rotation applied = qpos - ref
         T sn, cs;
-        sincos_f(th, sn, cs);
+        if (sc) { sn = sc[2 * i]; cs = sc[2 * i + 1]; }
+        else sincos_f(q[i] - T(L.ref), sn, cs);      // rotation applied = qpos - ref
         V3T<T> p = pp + rot(Ep, ld3t<T>(Lm.pos));
         V3T<T> tx = fma3(T(Lm.Q[0]), Ep.ex, fma3(T(Lm.Q[3]), Ep.ey, T(Lm.Q[6]) * Ep.ez));
         V3T<T> ty = fma3(T(Lm.Q[1]), Ep.ex, fma3(T(Lm.Q[4]), Ep.ey, T(Lm.Q[7]) * Ep.ez));
@@ -938,7 +953,12 @@ DEV V3 quad_sum(V3 a) { return v3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); 
 DEV void quad_sum(Sym3 &a) { a.xx = quad_sum(a.xx); a.yy = quad_sum(a.yy); a.zz = quad_sum(a.zz); a.xy = quad_sum(a.xy); a.xz = quad_sum(a.xz); a.yz = quad_sum(a.yz); }
 DEV void quad_sum(Sym6 &a) { quad_sum(a.AA); quad_sum(a.LL); a.AL.r0 = quad_sum(a.AL.r0); a.AL.r1 = quad_sum(a.AL.r1); a.AL.r2 = quad_sum(a.AL.r2); }
 
-struct LegState { float q[3], qd[3], act[3], u[3]; };
+struct LegState {
+    float q[3], qd[3], act[3], u[3];
+#ifdef QG_INCR_SINCOS
+    float sc[6];      // sin, cos of (q[i] - ref_i), advanced with the hinge
+#endif
+};
 
 // Ordered for low register pressure: the leg pass (the widest live set) runs first with only the base context alive;
 // the FRAME terms are built afterwards; sensors go straight to the LDS tile; the rotation is rebuilt at integration.
@@ -975,10 +995,18 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         if constexpr (BAKED) {
             // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
             Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
+#ifdef QG_INCR_SINCOS
+            leg_pass<float, true, true, LOWREG, DIET>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
+#else
             leg_pass<float, true, true, LOWREG, DIET>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+#endif
         } else {
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+#ifdef QG_INCR_SINCOS
+            leg_pass<float, false, false, LOWREG, DIET>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
+#else
             leg_pass<float, false, false, LOWREG, DIET>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
+#endif
         }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
@@ -1037,6 +1065,9 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         for (int r = 0; r < 6; ++r) acc = fmaf(-Y[i][r], x6[r], acc);
         L.qd[i] = fmaf(h, acc, L.qd[i]);
         L.q[i] = fmaf(h, L.qd[i], L.q[i]);
+#ifdef QG_INCR_SINCOS
+        hinge_advance(h * L.qd[i], L.sc[2 * i], L.sc[2 * i + 1]);
+#endif
         L.act[i] = fmaf(L.u[i] - L.act[i], link_of<BAKED>(C, k, i).act_decay, L.act[i]);
     }
     {
@@ -1119,6 +1150,9 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         L.q[i] = P.st.qpos[(7 + j) * n + env];
         L.qd[i] = P.st.qvel[(6 + j) * n + env];
         L.act[i] = P.st.act[j * n + env];
+#ifdef QG_INCR_SINCOS
+        sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
+#endif
     }
     if constexpr (WALK) {
         // every state value is in its register before the first store of the task layer is issued: the waits for those loads
@@ -1193,7 +1227,12 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
                 B.pw = v3(keep[0], keep[1], keep[2]); B.qw = keep[3]; B.qx = keep[4]; B.qy = keep[5]; B.qz = keep[6];
                 B.vw = v3(keep[7], keep[8], keep[9]); B.wb = v3(keep[10], keep[11], keep[12]);
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { L.q[i] = keep[13 + i]; L.qd[i] = keep[16 + i]; L.act[i] = keep[19 + i]; L.u[i] = keep[22 + i]; }
+                for (int i = 0; i < 3; ++i) {
+                    L.q[i] = keep[13 + i]; L.qd[i] = keep[16 + i]; L.act[i] = keep[19 + i]; L.u[i] = keep[22 + i];
+#ifdef QG_INCR_SINCOS
+                    sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
+#endif
+                }
             }
         }
         asm volatile("" : "+v"(env_e), "+v"(k_e));

@@ -519,3 +519,62 @@ def test_masked_reset_keeps_the_batch_seed(oracle):
         a = 2 * np.pi * oracle.uniform(1234, base + i, 1 if mask[i] else 0)
         assert np.allclose(qpos[i, [3, 6]], [np.cos(a / 2), np.sin(a / 2)], atol=2e-7), i
     sim.close()
+
+
+def _one_step_against_oracle(oracle, n, seed, mapping, sensor_lag=1, frame_skip=4):
+    """n seeded states (tools/make_golden.sample_states), one env-step through `mapping` and through the oracle; returns nothing,
+    asserts the stated tolerances on state, observation, reward."""
+    from quadruped_gym_amd.sim import BatchedSim
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_golden import sample_states
+    model, otask = oracle.default_model(), configure(oracle.default_task(), "A")
+    otask.sensor_lag, otask.frame_skip = sensor_lag, frame_skip
+    qpos, qvel, act, nstep = sample_states(model, otask, n, seed=seed)
+    actions = np.random.default_rng(seed).uniform(-1, 1, (n, 12)).astype(np.float32)
+    b = oracle.Batch(model, otask, n)
+    b.set_state(qpos.astype(np.float64), qvel.astype(np.float64), act.astype(np.float64), None, nstep)
+    obs_o, rew_o, done_o, _ = b.step(actions.astype(np.float64))
+    q_o, v_o, a_o, _, _ = b.get_state()
+    task = configure(_abi.default_task(), "A")
+    task.sensor_lag, task.frame_skip = sensor_lag, frame_skip
+    sim = BatchedSim(n, task=task)
+    sim.set_mapping(mapping)
+    sim.set_state(qpos, qvel, act, None, nstep)
+    obs, rew, done, _ = sim.step(actions)
+    q1, v1, a1, _, _ = sim.get_state()
+    sim.close()
+    t = TOL["A"]
+    mask = np.ones(33, bool)
+    mask[12:15] = False
+    close(obs[:, mask], obs_o[:, mask], t["obs"], "obs")
+    close(obs[:, 12:15], obs_o[:, 12:15], t["accel"], "accelerometer")
+    close(rew, rew_o, t["reward"], "reward")
+    close(q1, q_o, t["qpos"], "qpos")
+    close(v1, v_o, t["qvel"], "qvel")
+    close(a1, a_o, t["act"], "act")
+    return obs, obs_o
+
+
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+def test_unlagged_sensors_match_oracle(oracle, mapping):
+    """task.sensor_lag = 0 (an option beyond the reference, whose observation always lags by one substep): the sensors describe
+    the state the step ends in -- one extra forward pass whose state changes are discarded.  The state must advance exactly as
+    with lagged sensors, the observation must be the oracle's un-lagged one and differ from the lagged one."""
+    obs0, ref0 = _one_step_against_oracle(oracle, 150, 77, MAPPINGS[mapping], sensor_lag=0)
+    obs1, ref1 = _one_step_against_oracle(oracle, 150, 77, MAPPINGS[mapping], sensor_lag=1)
+    assert np.abs(ref0[:, 21:24] - ref1[:, 21:24]).max() > 1e-3         # world linear velocity: one substep apart
+    assert np.abs(obs0[:, 21:24] - obs1[:, 21:24]).max() > 1e-3
+
+
+@pytest.mark.parametrize("lag", [1, 0])
+@pytest.mark.parametrize("wpe", [2, 3, 4])
+def test_register_capped_quad_variants_match_oracle(oracle, wpe, lag):
+    """The one-leg-per-lane kernel exists in four register budgets (1..4 waves per SIMD; AUTO uses 1 up to 16 384 envs and 2
+    above, the 3 / 4-wave forms are kept for the occupancy measurement of profiles/r02/wpe_ab.txt and use a different loop
+    structure -- state parked in LDS for un-lagged sensors, compact per-link inertias).  QG_QUAD_WPE selects one at qg_create."""
+    os.environ["QG_QUAD_WPE"] = str(wpe)
+    try:
+        _one_step_against_oracle(oracle, 200, 500 + wpe, _abi.MAP_QUAD, sensor_lag=lag)
+    finally:
+        os.environ.pop("QG_QUAD_WPE", None)
