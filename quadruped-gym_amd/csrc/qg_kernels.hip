@@ -955,9 +955,7 @@ DEV void quad_sum(Sym6 &a) { quad_sum(a.AA); quad_sum(a.LL); a.AL.r0 = quad_sum(
 
 struct LegState {
     float q[3], qd[3], act[3], u[3];
-#ifdef QG_INCR_SINCOS
     float sc[6];      // sin, cos of (q[i] - ref_i), advanced with the hinge
-#endif
 };
 
 // Ordered for low register pressure: the leg pass (the widest live set) runs first with only the base context alive;
@@ -995,18 +993,10 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         if constexpr (BAKED) {
             // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
             Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
-#ifdef QG_INCR_SINCOS
             leg_pass<float, true, true, LOWREG, DIET>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
-#else
-            leg_pass<float, true, true, LOWREG, DIET>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
-#endif
         } else {
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-#ifdef QG_INCR_SINCOS
             leg_pass<float, false, false, LOWREG, DIET>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
-#else
-            leg_pass<float, false, false, LOWREG, DIET>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj);
-#endif
         }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
@@ -1065,9 +1055,7 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         for (int r = 0; r < 6; ++r) acc = fmaf(-Y[i][r], x6[r], acc);
         L.qd[i] = fmaf(h, acc, L.qd[i]);
         L.q[i] = fmaf(h, L.qd[i], L.q[i]);
-#ifdef QG_INCR_SINCOS
         hinge_advance(h * L.qd[i], L.sc[2 * i], L.sc[2 * i + 1]);
-#endif
         L.act[i] = fmaf(L.u[i] - L.act[i], link_of<BAKED>(C, k, i).act_decay, L.act[i]);
     }
     {
@@ -1134,7 +1122,9 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
             wprev[i] = WK.S.prev_ctrl[tt[i]];         // previous_ctrl of the control cost (:260-262)
         }
         walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
-        if (k == 0) win = walk_env_load(WK.S, n, env);  // what the reward epilogue reads: fetched now, behind the physics
+        if constexpr (WPE == 1) {
+            if (k == 0) win = walk_env_load(WK.S, n, env);  // what the reward epilogue reads: fetched now, behind the physics
+        }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1150,9 +1140,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
         L.q[i] = P.st.qpos[(7 + j) * n + env];
         L.qd[i] = P.st.qvel[(6 + j) * n + env];
         L.act[i] = P.st.act[j * n + env];
-#ifdef QG_INCR_SINCOS
         sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
-#endif
     }
     if constexpr (WALK) {
         // every state value is in its register before the first store of the task layer is issued: the waits for those loads
@@ -1229,9 +1217,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     L.q[i] = keep[13 + i]; L.qd[i] = keep[16 + i]; L.act[i] = keep[19 + i]; L.u[i] = keep[22 + i];
-#ifdef QG_INCR_SINCOS
                     sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
-#endif
                 }
             }
         }
@@ -1289,6 +1275,14 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
     }
     if constexpr (WALK) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (WPE > 1) {       // two waves share the SIMD: read the task state again here (the other wave covers the latency)
+#pragma unroll                        // instead of carrying 21 values through the substep loop
+            for (int i = 0; i < 3; ++i) {
+                const int t = (3 * k_e + i) * n + env_e;
+                wprev[i] = WK.S.prev_ctrl[t]; wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t];
+            }
+            if (lead) win = walk_env_load(WK.S, n, env_e);
+        }
         if (live) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) walk_channel_terms(WK.P, WK.S, n, env_e, 3 * k_e + i, aclip[i], wprev[i], wf[i], wa[i], sum);
@@ -1366,7 +1360,7 @@ DEV Sym6 hpsum(const Sym6T<f2> &a) {
 }
 DEV SV hpsum(const SVT<f2> &v) { SV r = {pair_sum(hsum(v.a)), pair_sum(hsum(v.l))}; return r; }
 
-struct LegPair { f2 q[3], qd[3], act[3], u[3]; };
+struct LegPair { f2 q[3], qd[3], act[3], u[3], sc[6]; };   // sc: sin, cos of (q[i] - ref_i) of both legs, advanced with the hinges
 
 DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, bool want_sensors, float *__restrict__ row, int half, float &zaxis_z) {
     const float h = C.h;
@@ -1398,7 +1392,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
         Sym6T<f2> Ic2, YFt2;
         SVT<f2> fc2, F2[3], Fu2;
         f2 Hd[3], H01, H02, H12, bj[3];
-        leg_pass<f2, true, true, false>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic2, fc2, F2, Hd, H01, H02, H12, bj);
+        leg_pass<f2, true, true, false>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic2, fc2, F2, Hd, H01, H02, H12, bj, L.sc);
         leg_eliminate<f2>(F2, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt2, Fu2);
         sub(Ic2, YFt2);                     // the two legs' Schur complements
         Ic = hpsum(Ic2);                    // sum over the two legs of the lane and over the two lanes of the env
@@ -1449,6 +1443,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
         for (int r = 0; r < 6; ++r) acc = fma_(-Y[i][r], f2(x6[r]), acc);
         L.qd[i] = fma_(f2(h), acc, L.qd[i]);
         L.q[i] = fma_(f2(h), L.qd[i], L.q[i]);
+        hinge_advance(f2(h) * L.qd[i], L.sc[2 * i], L.sc[2 * i + 1]);
         L.act[i] = fma_(L.u[i] - L.act[i], f2(C.link[i].act_decay), L.act[i]);
     }
     {
@@ -1500,6 +1495,8 @@ __global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *
         }
     }
     ssq = pair_sum(ssq);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sincos_f(L.q[i] - f2(C.link[i].ref), L.sc[2 * i], L.sc[2 * i + 1]);
 
     float *srow = tile + el * 35;
     float zaxis_z = 1.f;
