@@ -234,3 +234,35 @@ def test_walking_facades_refuse_custom_callables_and_do_not_auto_reset():
     obs, _ = env.reset()
     assert env._vec._sim.get_state()[4][0] == 0 and not obs.any()
     env.close()
+
+
+@pytest.mark.gpu
+def test_set_task_on_a_live_handle():
+    """qg_set_task: what assigning env.reward_fns / env.termination_fns / env.max_time after construction does in the reference
+    (README.md:74-89).  Takes effect from the next step; obs_mode is fixed at creation; refused while a walking layer is bound."""
+    import ctypes as C
+    from quadruped_gym_amd._abi import QuadGymError, check, load_library
+    from quadruped_gym_amd.sim import BatchedSim
+    sim = BatchedSim(32)
+    a = np.full((32, 12), 0.5, np.float32)
+    r0 = sim.step(a, want_components=True)
+    assert np.allclose(r0[3][:, 2], 1.0) and not r0[2].any()
+    t = _abi.default_task()
+    t.alive_bonus, t.w_ctrl, t.max_time = 3.0, 0.0, 0.03          # time limit now ends the episode at 15 substeps (nstep is 4)
+    sim.set_task(t)
+    r1 = sim.step(a, want_components=True)                        # nstep 8
+    assert np.allclose(r1[3][:, 2], 3.0) and not r1[3][:, 1].any() and not r1[2].any()
+    sim.step(a)                                                   # 12
+    assert sim.step(a)[2].all()                                   # 16 >= 15
+    t2 = _abi.default_task()
+    t2.obs_mode = _abi.OBS_IMU
+    with pytest.raises(QuadGymError, match="obs_mode"):
+        sim.set_task(t2)
+    w = C.c_void_p()
+    lib = load_library()
+    check(lib.qg_walk_create(sim._h, None, C.byref(w)), "qg_walk_create")
+    with pytest.raises(QuadGymError, match="walking task layer"):
+        sim.set_task(_abi.default_task())
+    check(lib.qg_walk_destroy(w), "qg_walk_destroy")
+    sim.set_task(_abi.default_task())
+    sim.close()
