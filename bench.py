@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="G",
                     help="capture G env-steps (kernel + per-step collective, double-buffered) into one hipGraph and replay it; "
                          "steps and warmup are rounded up to multiples of G.  Validated with a 1-rank RCCL group only: opt-in")
-    ap.add_argument("--mapping", choices=["auto", "lane", "quad", "pair"], default="auto", help="work mapping of the step kernel")
+    ap.add_argument("--mapping", choices=["auto", "lane", "quad", "pair", "link"], default="auto", help="work mapping of the step kernel")
     ap.add_argument("--exchange", choices=["auto", "eager"], default="auto",
                     help="multi-GPU only.  eager: kernel launch + asynchronous RCCL gather issued per step from the host (~36 us of host "
                          "work per step).  auto (default): time the eager loop first, then ALSO try the same K steps as replays of a "
@@ -209,9 +209,10 @@ def main():
     sim = BatchedSim(n, device=local_rank, model=model, task=task, env_index_base=rank * n)
     # data.ctrl is written back every step, as the reference's step maintains it (quadruped.py:164): the timed region skips nothing
     sim.set_track_ctrl(not args.no_track_ctrl)
-    sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}[args.mapping])
+    sim.set_mapping({"auto": _abi.MAP_AUTO, "lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR, "link": _abi.MAP_LINK}[args.mapping])
     mapping_name = {_abi.MAP_LANE: "one env per lane", _abi.MAP_QUAD: "one leg per lane (4 lanes per env)",
-                    _abi.MAP_PAIR: "two legs per lane, packed f32 (2 lanes per env)"}[sim.mapping]
+                    _abi.MAP_PAIR: "two legs per lane, packed f32 (2 lanes per env)",
+                    _abi.MAP_LINK: "one link per lane (16 lanes per env)"}[sim.mapping]
     sim.reset(seed=0, flags=task.reset_flags)
     od = sim.obs_dim
     row = od + 2
@@ -373,9 +374,10 @@ def main():
     qpos = sim.get_state()[0]
     healthy = bool(np.isfinite(qpos).all())
 
-    MAP_KEY = {_abi.MAP_LANE: "lane", _abi.MAP_QUAD: "quad", _abi.MAP_PAIR: "pair"}
-    MAP_KERNEL = {_abi.MAP_LANE: "qg_step_kernel", _abi.MAP_QUAD: "qg_step_kernel_quad", _abi.MAP_PAIR: "qg_step_kernel_pair"}
-    MAP_ENVS_PER_WAVE = {_abi.MAP_LANE: 64, _abi.MAP_QUAD: 16, _abi.MAP_PAIR: 32}
+    MAP_KEY = {_abi.MAP_LANE: "lane", _abi.MAP_QUAD: "quad", _abi.MAP_PAIR: "pair", _abi.MAP_LINK: "link"}
+    MAP_KERNEL = {_abi.MAP_LANE: "qg_step_kernel", _abi.MAP_QUAD: "qg_step_kernel_quad", _abi.MAP_PAIR: "qg_step_kernel_pair",
+                  _abi.MAP_LINK: "qg_step_kernel_link"}
+    MAP_ENVS_PER_WAVE = {_abi.MAP_LANE: 64, _abi.MAP_QUAD: 16, _abi.MAP_PAIR: 32, _abi.MAP_LINK: 4}
     def make_line(dt, kernel_ms, exchange_mode):
         # HBM traffic per launch: committed rocprofv3 PMC measurement of this same configuration, when there is one
         traffic, valu, flops = None, None, None

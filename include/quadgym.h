@@ -71,6 +71,8 @@ extern "C" {
 #define QG_MAP_QUAD 2    /* one leg per lane, four lanes per environment (16 envs per wave), any model numbers */
 #define QG_MAP_PAIR 3    /* two legs per lane as packed FP32 pairs, two lanes per environment (32 envs per wave);
                             compiled-in robot only: qg_set_mapping refuses it for other model numbers */
+#define QG_MAP_LINK 4    /* one link per lane, sixteen lanes per environment (4 envs per wave); compiled-in robot and the
+                            reference's lagged sensors only (otherwise the request falls back to QUAD) */
 
 /* qg_reset flags */
 #define QG_RESET_RANDOM_YAW 1u   /* walking_quad.py:68-75: qpos[3:7] = [cos a/2, 0, 0, sin a/2], a ~ U(0, 2 pi) */

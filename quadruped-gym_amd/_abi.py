@@ -14,7 +14,7 @@ OBS_FULL, OBS_IMU = 0, 1
 RESET_RANDOM_YAW = 1
 RESET_JOINT_JITTER = 2
 CMD_FIXED_HEADING, CMD_FIXED_VELOCITY_ANGLE, CMD_FIXED_SPEED = 1, 2, 4
-MAP_AUTO, MAP_LANE, MAP_QUAD, MAP_PAIR = 0, 1, 2, 3
+MAP_AUTO, MAP_LANE, MAP_QUAD, MAP_PAIR, MAP_LINK = 0, 1, 2, 3, 4
 OBS_DIM = {OBS_FULL: 33, OBS_IMU: 21}
 
 

@@ -18,6 +18,7 @@
 #include "../../include/qg_model_data.h"
 // the kernels are compiled in the same translation unit (one code object, no -fgpu-rdc)
 #include "qg_kernels.hip"
+#include "qg_kernel_link.hip"
 #include "qg_walk.hip"
 #include "qg_po.hip"
 #include "qg_tables.h"
@@ -235,6 +236,10 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
 static int effective_mapping(const qg_sim *s) {
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
     if (s->mapping == QG_MAP_PAIR) return s->baked ? QG_MAP_PAIR : QG_MAP_QUAD;
+    if (s->mapping == QG_MAP_LINK) return (s->baked && s->task.sensor_lag) ? QG_MAP_LINK : QG_MAP_QUAD;
+    // up to 4096 envs (1024 waves of the one-link-per-lane kernel = one per SIMD): 14.1 against 18.2 us per launch at 4096 envs; above,
+    // a second wave per SIMD doubles its time (21.9 us at 5120 envs) and the one-leg-per-lane kernel is ahead (profiles/r02/map_sweep.txt)
+    if (s->baked && s->task.sensor_lag && s->n <= 1024 * QGK_LINK_ENVS) return QG_MAP_LINK;
     if (s->baked && s->n > 1024 * QGK_QUAD_ENVS && (s->n <= 1024 * QGK_PAIR_ENVS || s->n >= 1792 * QGK_PAIR_ENVS)) return QG_MAP_PAIR;
     return QG_MAP_QUAD;
 }
@@ -256,13 +261,21 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.seed = s->seed;
     P.env_index_base = s->env_index_base;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
-    const int emap = walk ? QG_MAP_QUAD : effective_mapping(s);
-    if (walk) {
+    const int emap = effective_mapping(s);
+    if (walk && emap == QG_MAP_LINK) {
+        const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
+        int lblocks = (s->n + per_block - 1) / per_block;
+        hipLaunchKernelGGL(qg_step_kernel_link<true>, dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, *walk);
+    } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
         if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
         else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
         else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
+    } else if (emap == QG_MAP_LINK) {
+        const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
+        int lblocks = (s->n + per_block - 1) / per_block;
+        hipLaunchKernelGGL(qg_step_kernel_link<false>, dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, KWalkNone{});
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         hipLaunchKernelGGL(qg_step_kernel_pair, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
@@ -392,7 +405,8 @@ extern "C" int qg_set_mapping(qg_sim *s, int32_t mapping) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     if (mapping == QG_MAP_PAIR && !s->baked)
         return fail(QG_ERR_ARG, "qg_set_mapping: the two-legs-per-lane kernel serves the compiled-in robot only");
-    if (mapping != QG_MAP_AUTO && mapping != QG_MAP_LANE && mapping != QG_MAP_QUAD && mapping != QG_MAP_PAIR) return fail(QG_ERR_ARG, "qg_set_mapping: unknown mapping %d", mapping);
+    if (mapping != QG_MAP_AUTO && mapping != QG_MAP_LANE && mapping != QG_MAP_QUAD && mapping != QG_MAP_PAIR && mapping != QG_MAP_LINK)
+        return fail(QG_ERR_ARG, "qg_set_mapping: unknown mapping %d", mapping);
     s->mapping = mapping;
     return QG_OK;
 }
@@ -542,7 +556,7 @@ struct qg_walk {
 // and 57 343; an explicit QUAD: always): 23.3 us against 33.0 us for estimator -> physics -> reward at 4096 envs.  Where AUTO takes
 // the two-legs-per-lane kernel (16 385 .. 32 768 envs, >= 57 344) the three launches around it stay ahead (46.6 us against 52.5 us
 // fused at 32 768 envs); LANE / PAIR requests keep the three launches too.
-static bool walk_fused(const qg_sim *s) { return effective_mapping(s) == QG_MAP_QUAD; }
+static bool walk_fused(const qg_sim *s) { const int m = effective_mapping(s); return m == QG_MAP_QUAD || m == QG_MAP_LINK; }
 
 extern "C" int qg_walk_default_params(qg_walk_params *p) {
     if (!p) return fail(QG_ERR_ARG, "qg_walk_default_params: null output");

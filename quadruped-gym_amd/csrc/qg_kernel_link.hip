@@ -1,0 +1,486 @@
+// qg_kernel_link.hip -- env-step kernel, ONE LINK PER LANE: sixteen lanes per environment, four environments per wave.
+//
+// Why: up to 4096 envs the step time is the instruction count of ONE wave (a wave alone on its SIMD issues one VALU instruction per
+// >= 4.2 cycles whatever it is; 256 waves of the one-leg-per-lane kernel leave three quarters of the chip's 1024 SIMDs idle).  With
+// lane = 16 * env + 4 * leg + r, lane r in {0,1,2} owns LINK r of its leg (fema / shin / foot): the per-link work of a leg -- rigid
+// inertia about the FRAME origin, bias force, ground contact: two thirds of the leg pass -- runs once instead of three times per
+// wave, and 4096 envs fill all 1024 SIMDs.  Lane r = 3 of each leg is a spare: it carries the leg's quarter of the FRAME's
+// contact sample points.
+//   * kinematic chain: lane r executes chain steps 0..r (execution-masked), so after the chain every lane holds its own link's
+//     frame, velocity and bias acceleration; the chain's constants are literals (the quarter-turn frame makes every leg "leg 0");
+//   * link body: the same code in every lane on per-lane constants (mass, inertia, eight contact points of link r: held in
+//     registers, loaded once per launch);
+//   * backward pass inside the leg's four lanes with DPP quad_perm: composite inertia / force = suffix sums over r (two DPP adds per
+//     value), lane r forms column r of the leg's 3x3 joint block and its joint's servo / limit / damping terms, the nine numbers of
+//     the block and right-hand side are broadcast and every lane factors the same 3x3; the Schur complement is the sum of the rank-1
+//     terms z_r z_r^T / d_r, z = L^-1 F, one per lane;
+//   * the 33 base-block numbers (+ 4 of the FRAME contact) are summed over the env's 16 lanes with a symmetric DPP butterfly
+//     (quad_perm, quad_perm, row_half_mirror, row_mirror: every lane gets the bit-identical sum); base prelude, 6x6 solve and base
+//     integration run redundantly in the 16 lanes; the three hinges of a leg are integrated redundantly in its four lanes.
+// Compiled-in robot only, lagged sensors only (the reference's), at most one wave per SIMD: the launcher uses it for n <= 4096.
+#define QGK_LINK_ENVS 4     // envs per wave
+
+template <int CTRL> DEV float dpp_any(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of an env (one DPP row); symmetric at every level, so all 16 lanes hold identical bits
+DEV float env_sum(float x) {
+    x += dpp_any<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_any<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_any<0x141>(x);   // row_half_mirror
+    x += dpp_any<0x140>(x);   // row_mirror
+    return x;
+}
+DEV V3 env_sum(V3 a) { return v3(env_sum(a.x), env_sum(a.y), env_sum(a.z)); }
+// suffix sum over the links of a leg, lanes r = 0,1,2 (lane 3 must hold 0): lane r gets x_r + x_{r+1} + ... + x_2
+DEV float leg_suffix(float x) {
+    x += dpp_any<0xF9>(x);    // quad_perm [1,2,3,3]
+    x += dpp_any<0xFE>(x);    // quad_perm [2,3,3,3] of the partial sums: lane 0 adds (x2 + x3), lane 1 adds x3 = 0
+    return x;
+}
+DEV float leg_bcast0(float x) { return dpp_any<0x00>(x); }
+DEV float leg_bcast1(float x) { return dpp_any<0x55>(x); }
+DEV float leg_bcast2(float x) { return dpp_any<0xAA>(x); }
+
+// what link r needs as per-lane data (registers)
+struct LinkRegs {
+    float mass, ipos[3], inertia[6], cp[QGK_CP_LINK][3];
+    float lo, hi, damping, armature, kp, kv, gear, force_lo, force_hi;
+};
+struct LegJoints { float q[3], qd[3], act[3], u[3], sc[6]; };
+
+DEV float sel3(int r, float a, float b, float c) { return r == 0 ? a : (r == 1 ? b : c); }
+
+DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg, bool lead_env, BaseState &B, LegJoints &J, const LinkRegs &K,
+                      bool want_sensors, float *__restrict__ row, int kleg, float &zaxis_z) {
+    const float h = C.h;
+    const BaseCtx bc = base_prelude(C, B);
+    const V3 nb = bc.n;
+    if (want_sensors) {              // the step's sensordata describes the state at the start of its last substep
+        zaxis_z = bc.cz.z;
+        if (lead_leg) { row[3 * kleg + 0] = J.q[0]; row[3 * kleg + 1] = J.q[1]; row[3 * kleg + 2] = J.q[2]; }
+        if (lead_env) {
+            row[15] = B.wb.x; row[16] = B.wb.y; row[17] = B.wb.z;
+            row[18] = B.pw.x; row[19] = B.pw.y; row[20] = B.pw.z;
+            row[21] = B.vw.x; row[22] = B.vw.y; row[23] = B.vw.z;
+            row[24] = bc.cx.x; row[25] = bc.cx.y; row[26] = bc.cx.z;
+            row[27] = bc.cz.x; row[28] = bc.cz.y; row[29] = bc.cz.z;
+            row[30] = bc.vb.x; row[31] = bc.vb.y; row[32] = bc.vb.z;
+        }
+    }
+    const int rr = r < 2 ? r : 2;                    // the spare lane shadows link 2 through the chain
+    // ---- kinematic chain: lane r runs steps 0..r --------------------------------------------------------------------------
+    Fr Ep = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
+    V3 pp = v3(0.f, 0.f, 0.f);
+    SV vp = bc.V0, ap = bc.A0;
+    // every lane computes every step (S[i] of a descendant is never read by an ancestor's lane); only the carry -- frame, origin,
+    // velocity, bias acceleration: what the lane keeps as ITS link's -- is committed under the lane's mask
+    SV S[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const KLink &L = C.link[i];
+        const float sn = J.sc[2 * i], cs = J.sc[2 * i + 1];
+        V3 p = pp + rot(Ep, ld3(L.pos));
+        V3 tx = fma3(L.Q[0], Ep.ex, fma3(L.Q[3], Ep.ey, L.Q[6] * Ep.ez));
+        V3 ty = fma3(L.Q[1], Ep.ex, fma3(L.Q[4], Ep.ey, L.Q[7] * Ep.ez));
+        V3 tz = fma3(L.Q[2], Ep.ex, fma3(L.Q[5], Ep.ey, L.Q[8] * Ep.ez));
+        Fr E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
+        S[i].a = E.ez;
+        S[i].l = cross(p, E.ez);
+        SV v = {fma3(J.qd[i], S[i].a, vp.a), fma3(J.qd[i], S[i].l, vp.l)};
+        SV a;
+        a.a = fma3(J.qd[i], cross(v.a, S[i].a), ap.a);
+        a.l = fma3(J.qd[i], cross(v.a, S[i].l) + cross(v.l, S[i].a), ap.l);
+        if (i <= rr) { Ep = E; pp = p; vp = v; ap = a; }
+    }
+    const SV So = {Ep.ez, cross(pp, Ep.ez)};
+    // ---- this lane's link: rigid inertia about the FRAME origin (FRAME axes), bias force, ground contact -------------------------
+    Rigid Bi;
+    Bi.m = K.mass;
+    {
+        const Fr &E = Ep;
+        V3 c = pp + rot(E, v3(K.ipos[0], K.ipos[1], K.ipos[2]));
+        Bi.h = Bi.m * c;
+        V3 ux = fma3(K.inertia[0], E.ex, fma3(K.inertia[3], E.ey, K.inertia[4] * E.ez));
+        V3 uy = fma3(K.inertia[3], E.ex, fma3(K.inertia[1], E.ey, K.inertia[5] * E.ez));
+        V3 uz = fma3(K.inertia[4], E.ex, fma3(K.inertia[5], E.ey, K.inertia[2] * E.ez));
+        float hc = dot(Bi.h, c);
+        Bi.I.xx = fmaf(ux.x, E.ex.x, fmaf(uy.x, E.ey.x, uz.x * E.ez.x)) + hc - Bi.h.x * c.x;
+        Bi.I.yy = fmaf(ux.y, E.ex.y, fmaf(uy.y, E.ey.y, uz.y * E.ez.y)) + hc - Bi.h.y * c.y;
+        Bi.I.zz = fmaf(ux.z, E.ex.z, fmaf(uy.z, E.ey.z, uz.z * E.ez.z)) + hc - Bi.h.z * c.z;
+        Bi.I.xy = fmaf(ux.x, E.ex.y, fmaf(uy.x, E.ey.y, uz.x * E.ez.y)) - Bi.h.x * c.y;
+        Bi.I.xz = fmaf(ux.x, E.ex.z, fmaf(uy.x, E.ey.z, uz.x * E.ez.z)) - Bi.h.x * c.z;
+        Bi.I.yz = fmaf(ux.y, E.ex.z, fmaf(uy.y, E.ey.z, uz.y * E.ez.z)) - Bi.h.y * c.z;
+    }
+    SV f;
+    {
+        SV Iv = mul(Bi, vp), Ia = mul(Bi, ap);
+        f.a = Ia.a + cross(vp.a, Iv.a) + cross(vp.l, Iv.l);
+        f.l = Ia.l + cross(vp.a, Iv.l);
+    }
+    Sym6 A = sym6_of(Bi);
+    {
+        const float zo = B.pw.z + dot(nb, pp);
+        V3 nl = rotT(Ep, nb);
+        float wsum = 0.f;
+        V3 s = v3(0.f, 0.f, 0.f);
+        const float zb = C.contact_margin - zo;
+#pragma unroll
+        for (int i = 0; i < QGK_CP_LINK; ++i) contact_point(v3(K.cp[i][0], K.cp[i][1], K.cp[i][2]), nl, zb, wsum, s);
+        if (r == 3) wsum = 0.f;                     // the spare lane is no link (its mass and inertia are zero as well)
+        SV fe;
+        ContactDampT<float> cd;
+        contact_eval(wsum, s, Ep, pp, nb, vp, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, cd);
+        f.a = f.a - fe.a;
+        f.l = f.l - fe.l;
+        add_contact_damping(A, cd.mc, cd.w, cd.P, nb);
+    }
+    // FRAME contact: the spare lane of leg k evaluates that leg's quarter turn of the three base sample points
+    float wsumF = 0.f;
+    V3 sF = v3(0.f, 0.f, 0.f);
+    {
+        const float zbF = C.contact_margin - B.pw.z;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            V3 r0 = ld3(C.cp0[4 * o]);
+            contact_point(v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z), nb, zbF, wsumF, sF);
+        }
+        const float mF = r == 3 ? 1.f : 0.f;
+        wsumF *= mF; sF = mF * sF;
+    }
+    // ---- composite inertia and force of the subtree rooted at this link: suffix sums over the leg's lanes ----------------------------
+    Sym6 Ic;
+    SV fc;
+    Ic.AA.xx = leg_suffix(A.AA.xx); Ic.AA.yy = leg_suffix(A.AA.yy); Ic.AA.zz = leg_suffix(A.AA.zz);
+    Ic.AA.xy = leg_suffix(A.AA.xy); Ic.AA.xz = leg_suffix(A.AA.xz); Ic.AA.yz = leg_suffix(A.AA.yz);
+    Ic.AL.r0 = v3(leg_suffix(A.AL.r0.x), leg_suffix(A.AL.r0.y), leg_suffix(A.AL.r0.z));
+    Ic.AL.r1 = v3(leg_suffix(A.AL.r1.x), leg_suffix(A.AL.r1.y), leg_suffix(A.AL.r1.z));
+    Ic.AL.r2 = v3(leg_suffix(A.AL.r2.x), leg_suffix(A.AL.r2.y), leg_suffix(A.AL.r2.z));
+    Ic.LL.xx = leg_suffix(A.LL.xx); Ic.LL.yy = leg_suffix(A.LL.yy); Ic.LL.zz = leg_suffix(A.LL.zz);
+    Ic.LL.xy = leg_suffix(A.LL.xy); Ic.LL.xz = leg_suffix(A.LL.xz); Ic.LL.yz = leg_suffix(A.LL.yz);
+    fc.a = v3(leg_suffix(f.a.x), leg_suffix(f.a.y), leg_suffix(f.a.z));
+    fc.l = v3(leg_suffix(f.l.x), leg_suffix(f.l.y), leg_suffix(f.l.z));
+    // ---- column r of the leg's joint block, the joint's own terms -------------------------------------------------------------------
+    const SV F = mul(Ic, So);
+    const float Hc0 = dot(S[0], F), Hc1 = dot(S[1], F), Hc2 = dot(S[2], F);
+    const float tb = dot(So, fc);
+    float Hd_o, b_o;
+    {
+        const float q = sel3(rr, J.q[0], J.q[1], J.q[2]), qd = sel3(rr, J.qd[0], J.qd[1], J.qd[2]), act = sel3(rr, J.act[0], J.act[1], J.act[2]);
+        // position servo (quadruped.xml:10-37): force from the PRE-update activation
+        float force = K.kp * (act - K.gear * q) - (K.kv * K.gear) * qd;
+        const bool clamped = force <= K.force_lo || force >= K.force_hi;
+        force = fminf(fmaxf(force, K.force_lo), K.force_hi);
+        float dimp = K.damping + (clamped ? 0.f : K.kv * K.gear * K.gear);
+        float tau = K.gear * force - K.damping * qd;
+        // soft joint limits: one-sided spring + damper that ramps in with the penetration (continuous torque)
+        const float below = K.lo - q, above = q - K.hi;
+        const float pen = fmaxf(fmaxf(below, above), 0.f);
+        const float bl = C.limit_b * fminf(pen * C.limit_inv_ramp, 1.f);
+        const bool is_below = below > 0.f, is_above = !is_below && above > 0.f;
+        const float spring_b = C.limit_k * below, spring_a = C.limit_k * above;
+        const float tq_b = spring_b - bl * qd, tq_a = spring_a + bl * qd;
+        const bool free_b = tq_b < 0.f, free_a = tq_a < 0.f;          // leaving the limit fast: no pull-back, secant damping
+        const float lim_b = free_b ? 0.f : tq_b, be_b = free_b ? spring_b * rcp(qd) : bl;
+        const float lim_a = free_a ? 0.f : tq_a, be_a = free_a ? -spring_a * rcp(qd) : bl;
+        tau = tau + (is_below ? lim_b : 0.f) - (is_above ? lim_a : 0.f);
+        dimp = dimp + (is_below ? be_b : (is_above ? be_a : 0.f));
+        Hd_o = sel3(rr, Hc0, Hc1, Hc2) + K.armature + h * dimp;
+        b_o = tau - tb;
+    }
+    // ---- the 3x3 block and its right-hand side in every lane of the leg; LDL^T ----------------------------------------------------------
+    const float H00 = leg_bcast0(Hd_o), H01 = leg_bcast1(Hc0), H11 = leg_bcast1(Hd_o);
+    const float H02 = leg_bcast2(Hc0), H12 = leg_bcast2(Hc1), H22 = leg_bcast2(Hd_o);
+    const float b0 = leg_bcast0(b_o), b1 = leg_bcast1(b_o), b2 = leg_bcast2(b_o);
+    const float id0 = rcp(H00);
+    const float l10 = H01 * id0, l20 = H02 * id0;
+    const float d1 = fmaf(-l10, H01, H11), id1 = rcp(d1);
+    const float t21 = fmaf(-l20, H01, H12);
+    const float l21 = t21 * id1;
+    const float d2 = fmaf(-l21, t21, fmaf(-l20, H02, H22)), id2 = rcp(d2);
+    const float y0 = b0, y1 = fmaf(-l10, y0, b1), y2 = fmaf(-l21, y1, fmaf(-l20, y0, b2));     // y = L^-1 b
+    // ---- z = L^-1 F, row r in lane r: z0 = F0, z1 = F1 - l10 z0, z2 = F2 - l20 z0 - l21 z1 -----------------------------------------------
+    float z[6] = {F.a.x, F.a.y, F.a.z, F.l.x, F.l.y, F.l.z};
+    {
+        const float c0 = r == 1 ? l10 : (r == 2 ? l20 : 0.f), c1 = r == 2 ? l21 : 0.f;
+        float zb0[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zb0[i] = leg_bcast0(z[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) z[i] = fmaf(-c0, zb0[i], z[i]);
+        float zb1[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) zb1[i] = leg_bcast1(z[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) z[i] = fmaf(-c1, zb1[i], z[i]);
+    }
+    // ---- this lane's share of the base block: (r == 0: the leg's composite inertia and force) - z z^T / d_r, F u = sum_r z_r y_r / d_r ----
+    const float idr = sel3(rr, id0, id1, id2), yr = sel3(rr, y0, y1, y2);
+    float w[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = idr * z[i];
+    const float m0 = r == 0 ? 1.f : 0.f;
+    Sym6 Cn;
+    Cn.AA.xx = fmaf(m0, Ic.AA.xx, -(w[0] * z[0])); Cn.AA.yy = fmaf(m0, Ic.AA.yy, -(w[1] * z[1])); Cn.AA.zz = fmaf(m0, Ic.AA.zz, -(w[2] * z[2]));
+    Cn.AA.xy = fmaf(m0, Ic.AA.xy, -(w[0] * z[1])); Cn.AA.xz = fmaf(m0, Ic.AA.xz, -(w[0] * z[2])); Cn.AA.yz = fmaf(m0, Ic.AA.yz, -(w[1] * z[2]));
+    Cn.AL.r0 = v3(fmaf(m0, Ic.AL.r0.x, -(w[0] * z[3])), fmaf(m0, Ic.AL.r0.y, -(w[0] * z[4])), fmaf(m0, Ic.AL.r0.z, -(w[0] * z[5])));
+    Cn.AL.r1 = v3(fmaf(m0, Ic.AL.r1.x, -(w[1] * z[3])), fmaf(m0, Ic.AL.r1.y, -(w[1] * z[4])), fmaf(m0, Ic.AL.r1.z, -(w[1] * z[5])));
+    Cn.AL.r2 = v3(fmaf(m0, Ic.AL.r2.x, -(w[2] * z[3])), fmaf(m0, Ic.AL.r2.y, -(w[2] * z[4])), fmaf(m0, Ic.AL.r2.z, -(w[2] * z[5])));
+    Cn.LL.xx = fmaf(m0, Ic.LL.xx, -(w[3] * z[3])); Cn.LL.yy = fmaf(m0, Ic.LL.yy, -(w[4] * z[4])); Cn.LL.zz = fmaf(m0, Ic.LL.zz, -(w[5] * z[5]));
+    Cn.LL.xy = fmaf(m0, Ic.LL.xy, -(w[3] * z[4])); Cn.LL.xz = fmaf(m0, Ic.LL.xz, -(w[3] * z[5])); Cn.LL.yz = fmaf(m0, Ic.LL.yz, -(w[4] * z[5]));
+    // right-hand side share: -(m0 * fc + z_r y_r / d_r)
+    SV rhn = {v3(fmaf(-m0, fc.a.x, -(yr * w[0])), fmaf(-m0, fc.a.y, -(yr * w[1])), fmaf(-m0, fc.a.z, -(yr * w[2]))),
+              v3(fmaf(-m0, fc.l.x, -(yr * w[3])), fmaf(-m0, fc.l.y, -(yr * w[4])), fmaf(-m0, fc.l.z, -(yr * w[5])))};
+    // ---- base block: FRAME body + contact first (a wave-uniform branch), then the sums over the env's 16 lanes and the 6x6 solve, all
+    // redundant in the 16 lanes.  The sums come after the branch so that each DPP move sits in one basic block with the add that
+    // consumes it (the compiler fuses them into v_add_f32_dpp only then).
+    float x6[6];
+    {
+        SV p0;
+        Sym6 Ic0;
+        frame_body(C, bc, h, p0, Ic0);
+        wsumF = env_sum(wsumF);
+        if (__any(wsumF > 0.f)) {         // wave-uniform skip, as in the one-leg-per-lane kernel
+            sF = env_sum(sF);
+            Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+            SV fe;
+            contact_finish(wsumF, sF, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
+            p0.a = p0.a - fe.a;
+            p0.l = p0.l - fe.l;
+        }
+        Ic0.AA.xx += env_sum(Cn.AA.xx); Ic0.AA.yy += env_sum(Cn.AA.yy); Ic0.AA.zz += env_sum(Cn.AA.zz);
+        Ic0.AA.xy += env_sum(Cn.AA.xy); Ic0.AA.xz += env_sum(Cn.AA.xz); Ic0.AA.yz += env_sum(Cn.AA.yz);
+        Ic0.AL.r0 = Ic0.AL.r0 + env_sum(Cn.AL.r0); Ic0.AL.r1 = Ic0.AL.r1 + env_sum(Cn.AL.r1); Ic0.AL.r2 = Ic0.AL.r2 + env_sum(Cn.AL.r2);
+        Ic0.LL.xx += env_sum(Cn.LL.xx); Ic0.LL.yy += env_sum(Cn.LL.yy); Ic0.LL.zz += env_sum(Cn.LL.zz);
+        Ic0.LL.xy += env_sum(Cn.LL.xy); Ic0.LL.xz += env_sum(Cn.LL.xz); Ic0.LL.yz += env_sum(Cn.LL.yz);
+        SV b = {env_sum(rhn.a) - p0.a, env_sum(rhn.l) - p0.l};
+        base_solve(Ic0, b, x6);
+    }
+    const V3 wdot = v3(x6[0], x6[1], x6[2]);
+    const V3 acl = v3(x6[3], x6[4], x6[5]);
+    if (want_sensors && lead_env) {
+        row[12] = acl.x - bc.gb.x; row[13] = acl.y - bc.gb.y; row[14] = acl.z - bc.gb.z;   // accelerometer
+    }
+    // ---- hinge accelerations  qdd = H^-1 (b - F^T x)  with the factors every lane of the leg holds ---------------------------------------
+    {
+        const float g_o = fmaf(F.a.x, x6[0], fmaf(F.a.y, x6[1], fmaf(F.a.z, x6[2], fmaf(F.l.x, x6[3], fmaf(F.l.y, x6[4], F.l.z * x6[5])))));
+        const float r0 = b0 - leg_bcast0(g_o), r1 = b1 - leg_bcast1(g_o), r2 = b2 - leg_bcast2(g_o);
+        const float yy0 = r0, yy1 = fmaf(-l10, yy0, r1), yy2 = fmaf(-l21, yy1, fmaf(-l20, yy0, r2));
+        float qdd[3];
+        qdd[2] = yy2 * id2;
+        qdd[1] = fmaf(-l21, qdd[2], yy1 * id1);
+        qdd[0] = fmaf(-l20, qdd[2], fmaf(-l10, qdd[1], yy0 * id0));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            J.qd[i] = fmaf(h, qdd[i], J.qd[i]);
+            J.q[i] = fmaf(h, J.qd[i], J.q[i]);
+            hinge_advance(h * J.qd[i], J.sc[2 * i], J.sc[2 * i + 1]);
+            J.act[i] = fmaf(J.u[i] - J.act[i], C.link[i].act_decay, J.act[i]);
+        }
+    }
+    base_integrate(bc, h, wdot, acl, B);
+}
+
+// Workgroups of four waves (one per SIMD of a CU): a grid of 1024 one-wave workgroups measured 1.65 us more fixed time per launch
+// than 256 (kernel time against frame_skip, tools/fs_sweep.sh: intercept 5.75 vs 4.1 us) -- the dispatch of the workgroups
+// themselves; the waves do not interact (own tile rows, own envs).
+#define QGK_LINK_WAVES 4
+// WALK: the walking task layer fused in, exactly as in qg_step_kernel_quad<.., WALK> -- the lead lane of leg k plays the part of that
+// kernel's lane k (control channels 3k..3k+2), the env's lead lane evaluates the reward.
+template <bool WALK = false>
+__global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_link(const KTask *__restrict__ T, KStepArgs P,
+                                                                                  const typename WalkArgT<WALK>::type WK) {
+    __shared__ float tile_all[QGK_LINK_WAVES][QGK_LINK_ENVS * 35];
+    const KModel &C = QG_BAKED_MODEL;
+    const int lane = threadIdx.x & (QGK_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    float *tile = tile_all[wave];
+    const int r = lane & 3;                         // link of this lane (3: spare)
+    const int k = (lane >> 2) & 3;                  // leg
+    const int el = lane >> 4;                       // env within the wave
+    const int env0 = (blockIdx.x * QGK_LINK_WAVES + wave) * QGK_LINK_ENVS;
+    const int n = P.n;
+    const bool live = env0 + el < n;
+    const int env = live ? env0 + el : n - 1;       // tail lanes shadow the last env; their stores are masked
+    const bool lead_leg = r == 0, lead_env = (lane & 15) == 0;
+    const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
+    const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
+
+    // per-lane constants of link r: selected among the three links' LITERALS (two v_cndmask each, ~90 instructions once per launch)
+    // rather than loaded from a table -- a load round trip behind the state loads cost ~1 us of a 16 us launch.  The spare lane
+    // carries no mass and no inertia; its contact is switched off in the substep.
+    LinkRegs K;
+    {
+        const int rk = r < 2 ? r : 2;
+        const KLink &L0 = C.link[0], &L1 = C.link[1], &L2 = C.link[2];
+        const float ml = r < 3 ? 1.f : 0.f;
+#define QG_SEL(field) sel3(rk, L0.field, L1.field, L2.field)
+        K.mass = ml * QG_SEL(mass);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) K.ipos[i] = QG_SEL(ipos[i]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) K.inertia[i] = ml * QG_SEL(inertia[i]);
+#pragma unroll
+        for (int i = 0; i < QGK_CP_LINK; ++i) { K.cp[i][0] = QG_SEL(cp[i][0]); K.cp[i][1] = QG_SEL(cp[i][1]); K.cp[i][2] = QG_SEL(cp[i][2]); }
+        K.lo = QG_SEL(lo); K.hi = QG_SEL(hi); K.damping = QG_SEL(damping); K.armature = QG_SEL(armature); K.kp = QG_SEL(kp);
+        K.kv = QG_SEL(kv); K.gear = QG_SEL(gear); K.force_lo = QG_SEL(force_lo); K.force_hi = QG_SEL(force_hi);
+#undef QG_SEL
+    }
+
+    BaseState B;
+    B.pw = v3(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
+    B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
+    B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
+    B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    const int nstep0 = P.st.nstep[env];
+    LegJoints J;
+    float aclip[3];
+    // WALK: every load of the task layer goes out among the state loads, every store of its prologue part after the last of them
+    // (see qg_step_kernel_quad)
+    const bool wlead = live && lead_leg;
+    bool settle = false;
+    int calls = 0;
+    WalkEnvIn win = {};
+    const int tt[3] = {(3 * k + 0) * n + env, (3 * k + 1) * n + env, (3 * k + 2) * n + env};
+    float xx[3] = {0.f, 0.f, 0.f}, wprev[3] = {0.f, 0.f, 0.f}, wf[3] = {0.f, 0.f, 0.f}, wa[3] = {0.f, 0.f, 0.f}, a_eff[3] = {0.f, 0.f, 0.f};
+    WalkEstIn<3> west;
+    if constexpr (WALK) {
+        settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
+        calls = WK.S.calls[env];
+        if (lead_leg) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                xx[i] = P.st.ctrl[tt[i]];             // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+                wprev[i] = WK.S.prev_ctrl[tt[i]];     // previous_ctrl of the control cost (:260-262)
+            }
+            walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
+        }
+        if (lead_env) win = walk_env_load(WK.S, n, env);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = 3 * k + i;
+        float a_in = P.actions[(size_t)env * 12 + j];
+        if constexpr (WALK) {
+            if (settle) a_in = WK.P.joint_centers[j];                // the joint centres while the robot settles
+            a_eff[i] = a_in;
+        }
+        float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
+        aclip[i] = a;
+        J.u[i] = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
+        J.q[i] = P.st.qpos[(7 + j) * n + env];
+        J.qd[i] = P.st.qvel[(6 + j) * n + env];
+        J.act[i] = P.st.act[j * n + env];
+        sincos_f(J.q[i] - C.link[i].ref, J.sc[2 * i], J.sc[2 * i + 1]);
+    }
+    if constexpr (WALK) {
+        asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
+                     "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(J.q[0]), "v"(J.q[1]), "v"(J.q[2]), "v"(J.qd[0]), "v"(J.qd[1]), "v"(J.qd[2]),
+                     "v"(J.act[0]), "v"(J.act[1]), "v"(J.act[2]) : "memory");
+        if (wlead) {
+            walk_estimator_finish_n<3>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+#pragma unroll
+            for (int i = 0; i < 3; ++i) WK.S.eff_actions[(size_t)env * 12 + 3 * k + i] = a_eff[i];   // the action actually applied (the PO pack reads it)
+        }
+    }
+
+    float *srow = tile + el * 35;
+    float zaxis_z = 1.f;
+    const int fs = T->frame_skip;
+    asm volatile(".p2align 6");
+#pragma unroll 1
+    for (int s = 0; s < fs; ++s) substep_link(C, cm, sm, r, lead_leg, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
+    int nstep = nstep0 + fs;
+
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ssq = fmaf(aclip[i], aclip[i], ssq);
+    ssq = env_sum(lead_leg ? ssq : 0.f);
+    float c_fwd = T->w_forward * B.vw.x;
+    float c_ctl = T->w_ctrl * ssq;
+    float c_alive = T->alive_bonus;
+    float reward = c_fwd + c_ctl + c_alive;
+    bool done = nstep >= T->limit_substeps;
+    if (T->use_fall) done = done || (B.pw.z < T->fall_height);
+    {
+        float probe = J.q[0] + J.q[1] + J.q[2] + J.qd[0] + J.qd[1] + J.qd[2];
+        probe = env_sum(lead_leg ? probe : 0.f) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+        done = done || state_is_bad(probe);
+    }
+    const int od = T->obs_mode == 1 ? 21 : 33;
+    const int row = P.packed ? od + 2 : od;
+    if (T->use_flip) done = done || (zaxis_z < 0.f);              // walking_quad.py:156-160, on the step's sensordata
+    if (lead_env) {
+        if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
+        if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
+    }
+    __syncthreads();
+    {
+        const int live_envs = max(0, min(QGK_LINK_ENVS, n - env0));     // a whole wave may lie past the last env
+        const int total = live_envs * row;
+        float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
+        if (row == 35) {
+            for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+        } else {
+            for (int e = lane; e < total; e += QGK_WAVE) {
+                int er = e / row, ec = e - er * row;
+                dst[e] = tile[er * 35 + ec];
+            }
+        }
+    }
+    const bool lead = live && lead_env;
+    if (lead && !P.packed) {
+        if constexpr (!WALK) P.reward[env] = reward;
+        P.done[env] = done ? 1 : 0;
+    }
+    if constexpr (WALK) {
+        WalkSums sum = {0.f, 0.f, 0.f, 0.f};
+        if (wlead) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) walk_channel_terms(WK.P, WK.S, n, env, 3 * k + i, aclip[i], wprev[i], wf[i], wa[i], sum);
+        }
+        sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
+        if (lead) {
+            // the env's episode counter has not been advanced yet: it is the key of the episode that begins if this one ends
+            walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base,
+                            P.st.episode[env]);
+        }
+    }
+    if (lead && P.comps) {
+        P.comps[(size_t)env * 3 + 0] = c_fwd;
+        P.comps[(size_t)env * 3 + 1] = c_ctl;
+        P.comps[(size_t)env * 3 + 2] = c_alive;
+    }
+    const bool rst = done && T->auto_reset;
+    if (rst) {
+        B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+        B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+        if (T->reset_flags & 1u) {
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float sn, cs;
+            sincos_f(0.5f * a, sn, cs);
+            B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+        }
+        B.vw = v3(0.f, 0.f, 0.f);
+        B.wb = v3(0.f, 0.f, 0.f);
+        nstep = 0;
+    }
+    if (lead) {
+        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
+        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
+        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
+        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
+        P.st.nstep[env] = nstep;
+        if (rst) P.st.episode[env] += 1;
+    }
+    if (live && lead_leg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = 3 * k + i;
+            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : J.q[i];
+            P.st.qvel[(6 + j) * n + env] = rst ? 0.f : J.qd[i];
+            P.st.act[j * n + env] = rst ? 0.f : J.act[i];
+            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
+        }
+    }
+}

@@ -65,7 +65,7 @@ def test_bench_prints_one_contract_line_on_one_gpu():
     assert d["metric"] == "env_steps_per_sec" and d["dtype"] == "f32" and d["vs_baseline"] is None
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"] == "qg_step_kernel_quad"
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"] == "qg_step_kernel_link"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["state_finite"] is True
 
 

@@ -52,10 +52,10 @@ def gold():
     return dict(np.load(GOLD))
 
 
-MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}
+MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR, "link": _abi.MAP_LINK}
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 @pytest.mark.parametrize("case", ["A", "B"])
 def test_step_matches_golden_vectors(gold, case, mapping):
     """Every work mapping of the step kernel (one env per lane / one leg per lane / two legs per lane) against the fixture."""
@@ -89,7 +89,7 @@ def test_step_matches_golden_vectors(gold, case, mapping):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_step_matches_oracle_on_fresh_states(oracle, mapping):
     """Seeded states the fixture does not hold, through the device-pointer entry points."""
     import torch
@@ -237,7 +237,7 @@ def test_joint_jitter_reset_matches_oracle_stream(oracle):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_auto_reset_draws_match_oracle_stream(oracle, mapping):
     """The in-kernel auto-reset of each mapping applies the same yaw + hinge-jitter draws as the oracle's reset with the env's
     episode counter."""
@@ -268,7 +268,7 @@ def test_auto_reset_draws_match_oracle_stream(oracle, mapping):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_time_limit_terminates_and_auto_reset(mapping):
     """`time >= max_time` is reported as terminated on the exact substep the f64-accumulated clock
     crosses it (quadruped.py:149-151); with auto_reset the env restarts inside the same launch."""
@@ -294,7 +294,7 @@ def test_time_limit_terminates_and_auto_reset(mapping):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_full_size_invariants(mapping):
     """BASELINE config 2 size (4096 envs): properties that need no oracle."""
     import torch
@@ -330,7 +330,7 @@ def test_full_size_invariants(mapping):
     sim.close(); sim2.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_diverged_envs_are_reported_done_and_reset(mapping):
     """A state with NaN / Inf (here injected through set_state) must not linger: the env is reported done and,
     with auto_reset, restarts -- the counterpart of the engine's own bad-state reset."""
@@ -352,15 +352,26 @@ def test_diverged_envs_are_reported_done_and_reset(mapping):
 
 
 def test_auto_mapping_policy():
-    """AUTO = the measured optimum per batch size (profiles/r01/pair_sweep.txt); a modified robot never takes PAIR."""
+    """AUTO = the measured optimum per batch size (profiles/r01/pair_sweep.txt, profiles/r02/map_sweep.txt); a modified robot never
+    takes PAIR or LINK."""
     from quadruped_gym_amd.sim import BatchedSim
-    for n, want in ((4096, _abi.MAP_QUAD), (16384, _abi.MAP_QUAD), (16385, _abi.MAP_PAIR), (32768, _abi.MAP_PAIR), (32769, _abi.MAP_QUAD),
-                    (57343, _abi.MAP_QUAD), (57344, _abi.MAP_PAIR)):
+    for n, want in ((64, _abi.MAP_LINK), (4096, _abi.MAP_LINK), (4097, _abi.MAP_QUAD), (16384, _abi.MAP_QUAD), (16385, _abi.MAP_PAIR),
+                    (32768, _abi.MAP_PAIR), (32769, _abi.MAP_QUAD), (57343, _abi.MAP_QUAD), (57344, _abi.MAP_PAIR)):
         sim = BatchedSim(n)
         assert sim.baked and sim.mapping == want, (n, sim.mapping)
         sim.close()
+    t = _abi.default_task()
+    t.sensor_lag = 0                       # un-lagged sensors: the one-link-per-lane kernel does not serve them
+    sim = BatchedSim(2048, task=t)
+    assert sim.mapping == _abi.MAP_QUAD
+    sim.set_mapping(_abi.MAP_LINK)
+    assert sim.mapping == _abi.MAP_QUAD    # an explicit request falls back as well
+    sim.close()
     m = _abi.default_model()
     m.contact_friction = 0.7
+    sim = BatchedSim(2048, model=m)
+    assert not sim.baked and sim.mapping == _abi.MAP_QUAD
+    sim.close()
     sim = BatchedSim(20000, model=m)
     assert not sim.baked and sim.mapping == _abi.MAP_QUAD
     with pytest.raises(RuntimeError, match="compiled-in robot"):
@@ -374,10 +385,11 @@ def test_mappings_agree_with_each_other():
     so a 50-step rollout from reset stays within rounding-level drift of one another."""
     from quadruped_gym_amd.sim import BatchedSim
     n = 256
-    sims = [BatchedSim(n), BatchedSim(n), BatchedSim(n)]
+    sims = [BatchedSim(n), BatchedSim(n), BatchedSim(n), BatchedSim(n)]
     sims[0].set_mapping(_abi.MAP_LANE)
     sims[1].set_mapping(_abi.MAP_QUAD)
     sims[2].set_mapping(_abi.MAP_PAIR)
+    sims[3].set_mapping(_abi.MAP_LINK)
     rng = np.random.default_rng(21)
     for k in range(50):
         a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
@@ -385,13 +397,14 @@ def test_mappings_agree_with_each_other():
         if k == 0:
             assert np.allclose(o[0][0], o[1][0], atol=1e-4, rtol=1e-4)
             assert np.allclose(o[0][0], o[2][0], atol=1e-4, rtol=1e-4)
+            assert np.allclose(o[0][0], o[3][0], atol=1e-4, rtol=1e-4)
     q = [s.get_state()[0] for s in sims]
-    assert np.allclose(q[0], q[1], atol=5e-3) and np.allclose(q[0], q[2], atol=5e-3)
+    assert np.allclose(q[0], q[1], atol=5e-3) and np.allclose(q[0], q[2], atol=5e-3) and np.allclose(q[0], q[3], atol=5e-3)
     for s in sims:
         s.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_sharding_does_not_change_results(mapping):
     """Two handles of 128 envs with env_index_base 0 / 128 reproduce one handle of 256 bit for bit
     (per-env random streams are keyed by the global env index)."""
@@ -419,7 +432,7 @@ def test_sharding_does_not_change_results(mapping):
         s.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_non_finite_actions_stay_contained(mapping):
     """NaN / Inf in one env's action must not leak: the other envs step bit-identically to a clean run, +-Inf acts like the
     clip bound (quadruped.py:160), and the state of every env stays finite (a NaN command either clips or trips the
@@ -450,7 +463,7 @@ def test_non_finite_actions_stay_contained(mapping):
         s.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 @pytest.mark.parametrize("n", [1, 15, 33])
 def test_tiny_and_ragged_batches(oracle, mapping, n):
     """A single env, less than one quad-wave's 16 envs, and one env past the pair-wave's 32: the tail lanes shadow the last
@@ -556,7 +569,7 @@ def _one_step_against_oracle(oracle, n, seed, mapping, sensor_lag=1, frame_skip=
     return obs, obs_o
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad", "pair"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 def test_unlagged_sensors_match_oracle(oracle, mapping):
     """task.sensor_lag = 0 (an option beyond the reference, whose observation always lags by one substep): the sensors describe
     the state the step ends in -- one extra forward pass whose state changes are discarded.  The state must advance exactly as

@@ -10,16 +10,19 @@ from quadruped_gym_amd import _abi
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mapping", ["auto", "pair", "lane"])
+@pytest.mark.parametrize("mapping", ["auto", "quad", "pair", "lane"])
 @pytest.mark.parametrize("frame_skip", [4, 20])
 def test_walking_rewards_match_oracle(frame_skip, mapping):
-    """`auto` (= one leg per lane) runs the whole walking env-step as ONE launch (task layer fused into the step kernel);
-    `pair` / `lane` keep the three launches estimator -> physics -> reward.  Both go through the same device functions."""
+    """`auto` (= one link per lane at this size) and `quad` (one leg per lane) run the whole walking env-step as ONE launch (task
+    layer fused into the step kernel); `pair` / `lane` keep the three launches estimator -> physics -> reward.  All go through the
+    same device functions."""
     from quadruped_gym_amd.envs.walking import REWARD_KEYS, WalkingQuadrupedVecEnv
     n = 70
     settle = 0.05
     env = WalkingQuadrupedVecEnv(n, settling_time=settle, frame_skip=frame_skip, max_time=1000.0)
-    env._sim.set_mapping({"auto": _abi.MAP_AUTO, "pair": _abi.MAP_PAIR, "lane": _abi.MAP_LANE}[mapping])
+    env._sim.set_mapping({"auto": _abi.MAP_AUTO, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR, "lane": _abi.MAP_LANE}[mapping])
+    if mapping == "auto":
+        assert env._sim.mapping == _abi.MAP_LINK
     assert REWARD_KEYS == W.REWARD_KEYS
     dt = 0.002 * frame_skip
     o = W.WalkingOracle(n, dt, settling_time=settle)
