@@ -269,29 +269,45 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
-        if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
-        else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
-        else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, *walk);
+        const bool wg4 = qblocks > 256;             // four-wave workgroups for grids of more than 256 waves
+        dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
+        if (!s->baked) {
+            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk);
+            else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk);
+        } else if (wpe == 1) {
+            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk);
+            else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk);
+        } else {
+            hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk);
+        }
     } else if (emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
         hipLaunchKernelGGL(qg_step_kernel_link<false>, dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, KWalkNone{});
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
-        hipLaunchKernelGGL(qg_step_kernel_pair, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
+        if (pblocks > 256 && !getenv("QG_ONE_WAVE_WG"))
+            hipLaunchKernelGGL(qg_step_kernel_pair<4>, dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P);
+        else
+            hipLaunchKernelGGL(qg_step_kernel_pair<1>, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
     } else if (emap == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
+        const bool wg4 = qblocks > 256;             // four-wave workgroups for grids of more than 256 waves
+        dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
         if (s->baked) {
             const int wpe = s->quad_wpe ? s->quad_wpe : (one_wave ? 1 : 2);
-            if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            if (wpe == 1 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else if (wpe == 2 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
         } else {
             // tables in LDS: the 256-register cap spills 888 B per lane and measured 2x slower at every grid size (363 vs 741 us
             // at 262 144 envs), so any other robot runs the one-wave-per-SIMD form throughout
-            hipLaunchKernelGGL((qg_step_kernel_quad<1, false>), dim3(qblocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
         }
     } else if (s->baked)
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);

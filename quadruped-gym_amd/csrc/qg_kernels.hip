@@ -1079,22 +1079,26 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 // one launch: settling-time action mask and the estimator update of the lane's three control channels in the prologue (they
 // need data.ctrl of the PREVIOUS step, which is still in place there), ideal-position integration, the eleven reward terms and
 // the episode bookkeeping in the epilogue on the sensor row the wave has just staged in LDS.
-template <int WPE, bool BAKED, bool WALK = false>
-__global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
-                                                                     const typename WalkArgT<WALK>::type WK) {
-    __shared__ float tile[QGK_QUAD_ENVS * 35];
+// WAVES: waves per workgroup (1, or 4 = one per SIMD of a CU for grids of more than 256 waves: fewer workgroups to dispatch,
+// see qg_step_kernel_pair); the waves of a workgroup do not interact.
+template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1>
+__global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
+                                                                             const typename WalkArgT<WALK>::type WK) {
+    __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (QGK_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    float *tile = tile_all[wave];
     if constexpr (!BAKED) {
         const float *src = reinterpret_cast<const float *>(Mp);
         float *dst = reinterpret_cast<float *>(&smodel);
-        for (int i = lane; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * WAVES) dst[i] = src[i];
         __syncthreads();
     }
     const KModel &C = BAKED ? QG_BAKED_MODEL : smodel;
     const int k = lane & 3;                         // leg of this lane
     const int el = lane >> 2;                       // env within the wave
-    const int env0 = blockIdx.x * QGK_QUAD_ENVS;
+    const int env0 = (blockIdx.x * WAVES + wave) * QGK_QUAD_ENVS;
     const int n = P.n;
     const bool live = env0 + el < n;
     const int env = live ? env0 + el : n - 1;       // tail quads shadow the last env; their stores are masked
@@ -1263,7 +1267,7 @@ __global__ __launch_bounds__(QGK_WAVE, WPE) void qg_step_kernel_quad(const KMode
     }
     __syncthreads();
     {
-        const int live_envs = min(QGK_QUAD_ENVS, n - env0);
+        const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));      // a whole wave may lie past the last env
         const int total = live_envs * row;
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
         if (row == 35) {                       // rows were staged with a stride of 35 floats: the packed full layout is a straight copy
@@ -1463,13 +1467,19 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
 
 // One wave per SIMD by construction (381 registers): capping it to 256 for two resident waves spills 592 B per lane and
 // measured slower than this variant at every size (profiles/r01/pair_sweep.txt), so there is only this one.
-__global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P) {
-    __shared__ float tile[QGK_PAIR_ENVS * 35];
+// WAVES: waves per workgroup (1 or 4, one per SIMD of a CU; they do not interact).  A grid of 1024 one-wave workgroups costs ~1.6 us
+// more fixed time per launch than 256 four-wave ones (the dispatch of the workgroups themselves: tools/fs_sweep.sh on the
+// one-link-per-lane kernel), so grids of more than 256 waves are launched as four-wave workgroups.
+template <int WAVES>
+__global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P) {
+    __shared__ float tile_all[WAVES][QGK_PAIR_ENVS * 35];
     const KModel &C = QG_BAKED_MODEL;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (QGK_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    float *tile = tile_all[wave];
     const int half = lane & 1;                      // legs 2*half, 2*half + 1
     const int el = lane >> 1;                       // env within the wave
-    const int env0 = blockIdx.x * QGK_PAIR_ENVS;
+    const int env0 = (blockIdx.x * WAVES + wave) * QGK_PAIR_ENVS;
     const int n = P.n;
     const bool live = env0 + el < n;
     const int env = live ? env0 + el : n - 1;       // tail pairs shadow the last env; their stores are masked
@@ -1538,7 +1548,7 @@ __global__ __launch_bounds__(QGK_WAVE, 1) void qg_step_kernel_pair(const KTask *
     }
     __syncthreads();
     {
-        const int live_envs = min(QGK_PAIR_ENVS, n - env0);
+        const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));      // a whole wave may lie past the last env
         const int total = live_envs * row;
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
         if (row == 35) {
