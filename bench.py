@@ -421,7 +421,7 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_step * n,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "VALU-issue-bound path (no dense contraction): ~0.6 KB of state traffic per env-step against "
-                                 "~35 k VALU lane-instructions; the HBM fraction is small by construction"},
+                                 "tens of thousands of VALU lane-instructions; the HBM fraction is small by construction"},
         }
         if valu:
             # issue-rate view of the same launch: wave-instructions/s against 1024 SIMDs x (2.4 GHz / 2 cycles per wave64 VALU
@@ -436,7 +436,15 @@ def main():
             per = flops["flops_per_env_step"]
             tf = per * n / (kernel_ms * 1e-3) / 1e12
             line["roofline"]["fp32"] = {"flops_per_env_step": per, "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": tf / FP32_PEAK_TFLOPS, "flop_per_byte": per / bytes_step, "source": flops.get("source")}
+                                        "frac": tf / FP32_PEAK_TFLOPS, "flop_per_byte": per / bytes_step, "source": flops.get("source"),
+                                        "note": "hardware-counted flops of the kernel that ran, every lane included (work the mapping "
+                                                "replicates across lanes counts)"}
+            base = idx.get(f"flops_quad_fs{args.frame_skip}")
+            if base and sim.mapping != _abi.MAP_QUAD:
+                # the same physics with the least replication (one leg per lane): the flops the env-step needs rather than the ones executed
+                u = base["flops_per_env_step"] * n / (kernel_ms * 1e-3) / 1e12
+                line["roofline"]["fp32"]["least_replicated"] = {"flops_per_env_step": base["flops_per_env_step"], "achieved": u,
+                                                                "frac": u / FP32_PEAK_TFLOPS, "source": base.get("source")}
         line["config"]["ctrl_tracking"] = not args.no_track_ctrl
         if exchange_mode is not None:
             line["config"]["exchange"] = exchange_mode

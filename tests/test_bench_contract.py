@@ -23,7 +23,9 @@ def test_algorithmic_bytes_follow_survey_8d():
 def test_traffic_index_is_consistent():
     import json
     idx = json.load(open(os.path.join(ROOT, "profiles", "traffic_index.json")))
-    ent = idx["quad_n4096_fs4_obs33"]
+    for key in ("quad_n4096_fs4_obs33", "link_n4096_fs4_obs33"):
+        assert os.path.exists(os.path.join(ROOT, idx[key]["source"]))
+    ent = idx["link_n4096_fs4_obs33"]
     assert os.path.exists(os.path.join(ROOT, ent["source"]))
     # writes match the algorithmic 340 B per env plus the 48 B of data.ctrl the step maintains (quadruped.py:164; tracking is on in
     # the timed loop since round 2) and the rare reset bookkeeping
@@ -31,6 +33,7 @@ def test_traffic_index_is_consistent():
     assert 0.9 * 588 * 4096 < ent["hbm_bytes_per_launch"] < 2.0 * 588 * 4096
     fl = idx["flops_quad_fs4"]
     assert os.path.exists(os.path.join(ROOT, fl["source"])) and 30e3 < fl["flops_per_env_step"] < 80e3      # SURVEY 8(d) estimated ~50 kflop
+    assert 80e3 < idx["flops_link_fs4"]["flops_per_env_step"] < 160e3     # 16 lanes per env: the replicated base part and chain are counted
 
 
 import json

@@ -31,7 +31,7 @@ for fs in (4, 20):
     q_o, v_o, a_o, _, _ = b.get_state()
     airborne = int((q_o[:, 2] > 0.25).sum())
     print(f"\n## frame_skip {fs}: {n} states ({airborne} airborne after the step, the rest in ground contact); |qvel| up to {np.abs(v_o).max():.1f}")
-    for name, mp in (("lane", _abi.MAP_LANE), ("quad", _abi.MAP_QUAD), ("pair", _abi.MAP_PAIR)):
+    for name, mp in (("lane", _abi.MAP_LANE), ("quad", _abi.MAP_QUAD), ("pair", _abi.MAP_PAIR), ("link", _abi.MAP_LINK)):
         sim = BatchedSim(n, task=task)
         sim.set_mapping(mp)
         sim.set_state(qpos, qvel, act, None, nstep)

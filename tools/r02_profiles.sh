@@ -12,9 +12,10 @@ python bench.py --frame-skip 20 --obs-mode 1 --steps 1000 --warmup 100 --cpu-sec
 python bench.py --walking --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/r02/bench_walking.json 2>/dev/null; echo "walk rc=$?"
 python bench.py --walking --envs-per-gpu 32768 --steps 500 --warmup 50 --no-cpu-baseline > gpurun_out/r02/bench_walking_n32768.json 2>/dev/null; echo "walk32k rc=$?"
 python bench.py --no-track-ctrl --steps 2000 --warmup 200 --no-cpu-baseline > gpurun_out/r02/bench_cfg2_no_ctrl_tracking.json 2>/dev/null; echo "noctrl rc=$?"
-tools/profile_gpu.sh r02_quad_n4096
+tools/profile_gpu.sh r02_link_n4096
+tools/profile_gpu.sh r02_quad_n4096 --mapping quad
 tools/profile_gpu.sh r02_pair_n32768_yaw --envs-per-gpu 32768 --random-yaw
-tools/profile_gpu.sh r02_quad_n4096_fs20_imu --frame-skip 20 --obs-mode 1
+tools/profile_gpu.sh r02_link_n4096_fs20_imu --frame-skip 20 --obs-mode 1
 tools/profile_gpu.sh r02_walking_n4096 --walking
 python tools/parity_report.py 4096 > gpurun_out/r02/parity_report.txt 2>&1; echo "parity rc=$?"
 python tools/rollout_demo.py > gpurun_out/r02/rollout_demo.txt 2>&1

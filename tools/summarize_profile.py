@@ -15,9 +15,9 @@ def short(name):
 
 def main(src, dst_prefix):
     os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if stats:
-        rows = list(csv.reader(open(stats[0])))
+        rows = list(csv.reader(open(stats[-1])))            # the newest run (gpurun merges runs into the same directory)
         with open(dst_prefix + "_kernel_stats.csv", "w", newline="") as fh:
             w = csv.writer(fh)
             w.writerow(rows[0])
@@ -26,7 +26,8 @@ def main(src, dst_prefix):
                 w.writerow(r)
     pmc = {}
     for sub in ("pmc_sq", "pmc_fetch", "pmc_write", "pmc_flops"):
-        for path in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        paths = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+        for path in paths[-1:]:                               # the newest run only
             acc = {}
             for row in csv.DictReader(open(path)):
                 if "qg_step" in row["Kernel_Name"]:
