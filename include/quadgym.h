@@ -65,8 +65,8 @@ extern "C" {
 #define QG_OBS_IMU 1     /* jointpos 12 + accel 3 + gyro 3 + velocimeter 3 = 21 (BASELINE config 5) */
 
 /* work mappings of the step kernel (qg_set_mapping) */
-#define QG_MAP_AUTO 0    /* QUAD; the measured optimum per size: PAIR for the compiled-in robot when
-                            16384 < n_envs <= 32768 or n_envs >= 57344, QUAD otherwise */
+#define QG_MAP_AUTO 0    /* the measured optimum per size, for the compiled-in robot: LINK up to 4096 envs, QUAD up to 16384 and for
+                            32769..57343, PAIR for 16385..32768 and >= 57344; QUAD for any other model numbers */
 #define QG_MAP_LANE 1    /* one environment per wavefront lane (64 envs per wave), any model numbers */
 #define QG_MAP_QUAD 2    /* one leg per lane, four lanes per environment (16 envs per wave), any model numbers */
 #define QG_MAP_PAIR 3    /* two legs per lane as packed FP32 pairs, two lanes per environment (32 envs per wave);
