@@ -292,6 +292,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
                                                                                   const typename WalkArgT<WALK>::type WK) {
     __shared__ float tile_all[QGK_LINK_WAVES][QGK_LINK_ENVS * 35];
     const KModel &C = QG_BAKED_MODEL;
+    // the task constants into scalar registers up front: read where they are used, every read in the epilogue was its own
+    // scalar-load round trip in front of a wave that has nothing else to do
+    struct { int32_t frame_skip, limit_substeps, use_fall, use_flip, obs_mode, auto_reset; uint32_t reset_flags; float fall_height, w_forward, w_ctrl, alive_bonus;
+             const float *default_ctrl; } Tk = {T->frame_skip, T->limit_substeps, T->use_fall, T->use_flip, T->obs_mode, T->auto_reset, T->reset_flags,
+                                               T->fall_height, T->w_forward, T->w_ctrl, T->alive_bonus, T->default_ctrl};
     const int lane = threadIdx.x & (QGK_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     float *tile = tile_all[wave];
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
 
     float *srow = tile + el * 35;
     float zaxis_z = 1.f;
-    const int fs = T->frame_skip;
+    const int fs = Tk.frame_skip;
     asm volatile(".p2align 6");
 #pragma unroll 1
     for (int s = 0; s < fs; ++s) substep_link(C, cm, sm, r, lead_leg, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
@@ -396,20 +401,20 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
 #pragma unroll
     for (int i = 0; i < 3; ++i) ssq = fmaf(aclip[i], aclip[i], ssq);
     ssq = env_sum(lead_leg ? ssq : 0.f);
-    float c_fwd = T->w_forward * B.vw.x;
-    float c_ctl = T->w_ctrl * ssq;
-    float c_alive = T->alive_bonus;
+    float c_fwd = Tk.w_forward * B.vw.x;
+    float c_ctl = Tk.w_ctrl * ssq;
+    float c_alive = Tk.alive_bonus;
     float reward = c_fwd + c_ctl + c_alive;
-    bool done = nstep >= T->limit_substeps;
-    if (T->use_fall) done = done || (B.pw.z < T->fall_height);
+    bool done = nstep >= Tk.limit_substeps;
+    if (Tk.use_fall) done = done || (B.pw.z < Tk.fall_height);
     {
         float probe = J.q[0] + J.q[1] + J.q[2] + J.qd[0] + J.qd[1] + J.qd[2];
         probe = env_sum(lead_leg ? probe : 0.f) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
         done = done || state_is_bad(probe);
     }
-    const int od = T->obs_mode == 1 ? 21 : 33;
+    const int od = Tk.obs_mode == 1 ? 21 : 33;
     const int row = P.packed ? od + 2 : od;
-    if (T->use_flip) done = done || (zaxis_z < 0.f);              // walking_quad.py:156-160, on the step's sensordata
+    if (Tk.use_flip) done = done || (zaxis_z < 0.f);              // walking_quad.py:156-160, on the step's sensordata
     if (lead_env) {
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
@@ -451,11 +456,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         P.comps[(size_t)env * 3 + 1] = c_ctl;
         P.comps[(size_t)env * 3 + 2] = c_alive;
     }
-    const bool rst = done && T->auto_reset;
+    const bool rst = done && Tk.auto_reset;
     if (rst) {
         B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
         B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
-        if (T->reset_flags & 1u) {
+        if (Tk.reset_flags & 1u) {
             float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
             float sn, cs;
             sincos_f(0.5f * a, sn, cs);
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : J.q[i];
             P.st.qvel[(6 + j) * n + env] = rst ? 0.f : J.qd[i];
             P.st.act[j * n + env] = rst ? 0.f : J.act[i];
-            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[i];
+            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? Tk.default_ctrl[j] : aclip[i];
         }
     }
 }
