@@ -843,13 +843,14 @@ extern "C" int qg_walk_get_estimates(qg_walk *w, float *f_est, float *a_est, flo
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     int threads = 256;
-    struct { const float *src; float *dst; int width; } jobs[3] = {{w->st.f_est, f_est, 12}, {w->st.a_est, a_est, 12}, {w->st.ideal, ideal_xy, 2}};
-    for (auto &j : jobs) {
-        if (!j.dst) continue;
-        int total = s->n * j.width;
-        hipLaunchKernelGGL(qg_transpose_out, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, j.src, w->d_tmp, s->n, j.width);
+    // the estimates live env-major ([n][12]) on the device, as the caller wants them; the ideal position is [2][n]
+    if (f_est) HIP_TRY(hipMemcpy(f_est, w->st.f_est, (size_t)s->n * 12 * 4, hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    if (a_est) HIP_TRY(hipMemcpy(a_est, w->st.a_est, (size_t)s->n * 12 * 4, hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    if (ideal_xy) {
+        int total = s->n * 2;
+        hipLaunchKernelGGL(qg_transpose_out, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, (const float *)w->st.ideal, w->d_tmp, s->n, 2);
         HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
-        HIP_TRY(hipMemcpyAsync(j.dst, w->d_tmp, (size_t)total * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+        HIP_TRY(hipMemcpyAsync(ideal_xy, w->d_tmp, (size_t)total * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
         HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
     }
     return QG_OK;

@@ -285,8 +285,9 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
 // than 256 (kernel time against frame_skip, tools/fs_sweep.sh: intercept 5.75 vs 4.1 us) -- the dispatch of the workgroups
 // themselves; the waves do not interact (own tile rows, own envs).
 #define QGK_LINK_WAVES 4
-// WALK: the walking task layer fused in, exactly as in qg_step_kernel_quad<.., WALK> -- the lead lane of leg k plays the part of that
-// kernel's lane k (control channels 3k..3k+2), the env's lead lane evaluates the reward.
+// WALK: the walking task layer fused in as in qg_step_kernel_quad<.., WALK>, one control channel per lane: lane r < 3 of leg k owns
+// channel 3k + r (estimator update in the prologue, its terms of the reward sums in the epilogue), the env's lead lane evaluates
+// the reward.
 template <bool WALK = false>
 __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_link(const KTask *__restrict__ T, KStepArgs P,
                                                                                   const typename WalkArgT<WALK>::type WK) {
@@ -342,23 +343,21 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     float aclip[3];
     // WALK: every load of the task layer goes out among the state loads, every store of its prologue part after the last of them
     // (see qg_step_kernel_quad)
-    const bool wlead = live && lead_leg;
+    const bool wch = live && r < 3;                 // this lane owns control channel 3k + r
+    const int jch = 3 * k + (r < 3 ? r : 2);
     bool settle = false;
     int calls = 0;
     WalkEnvIn win = {};
-    const int tt[3] = {(3 * k + 0) * n + env, (3 * k + 1) * n + env, (3 * k + 2) * n + env};
-    float xx[3] = {0.f, 0.f, 0.f}, wprev[3] = {0.f, 0.f, 0.f}, wf[3] = {0.f, 0.f, 0.f}, wa[3] = {0.f, 0.f, 0.f}, a_eff[3] = {0.f, 0.f, 0.f};
-    WalkEstIn<3> west;
+    const int tt[1] = {env * 12 + jch};               // task state: [n][12]
+    float xx[1] = {0.f}, wprev = 0.f, wf[1] = {0.f}, wa[1] = {0.f}, a_eff[3] = {0.f, 0.f, 0.f};
+    WalkEstIn<1> west;
     if constexpr (WALK) {
         settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
         calls = WK.S.calls[env];
-        if (lead_leg) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                xx[i] = P.st.ctrl[tt[i]];             // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
-                wprev[i] = WK.S.prev_ctrl[tt[i]];     // previous_ctrl of the control cost (:260-262)
-            }
-            walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
+        if (r < 3) {
+            xx[0] = P.st.ctrl[jch * n + env];         // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+            wprev = WK.S.prev_ctrl[tt[0]];            // previous_ctrl of the control cost (:260-262)
+            walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west);
         }
         if (lead_env) win = walk_env_load(WK.S, n, env);
     }
@@ -382,10 +381,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
                      "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(J.q[0]), "v"(J.q[1]), "v"(J.q[2]), "v"(J.qd[0]), "v"(J.qd[1]), "v"(J.qd[2]),
                      "v"(J.act[0]), "v"(J.act[1]), "v"(J.act[2]) : "memory");
-        if (wlead) {
-            walk_estimator_finish_n<3>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
-#pragma unroll
-            for (int i = 0; i < 3; ++i) WK.S.eff_actions[(size_t)env * 12 + 3 * k + i] = a_eff[i];   // the action actually applied (the PO pack reads it)
+        if (wch) {
+            walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+            WK.S.eff_actions[(size_t)env * 12 + jch] = sel3(r, a_eff[0], a_eff[1], a_eff[2]);   // the action actually applied (the PO pack reads it)
         }
     }
 
@@ -440,10 +438,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     }
     if constexpr (WALK) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
-        if (wlead) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) walk_channel_terms(WK.P, WK.S, n, env, 3 * k + i, aclip[i], wprev[i], wf[i], wa[i], sum);
-        }
+        if (wch) walk_channel_terms(WK.P, WK.S, n, env, jch, sel3(r, aclip[0], aclip[1], aclip[2]), wprev, wf[0], wa[0], sum);
         sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
         if (lead) {
             // the env's episode counter has not been advanced yet: it is the key of the episode that begins if this one ends

@@ -1123,13 +1123,13 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     }
     // WALK: every load of the task layer goes out here, among the state loads, and every store of its prologue part comes after the
     // last load of the kernel's prologue (a load behind a store would wait for that store: vmcnt counts in order)
-    const int tt[3] = {(3 * k + 0) * n + env, (3 * k + 1) * n + env, (3 * k + 2) * n + env};
+    const int tt[3] = {env * 12 + 3 * k + 0, env * 12 + 3 * k + 1, env * 12 + 3 * k + 2};     // task state: [n][12]
     float xx[3] = {0.f, 0.f, 0.f}, wprev[3] = {0.f, 0.f, 0.f}, wf[3] = {0.f, 0.f, 0.f}, wa[3] = {0.f, 0.f, 0.f}, a_eff[3] = {0.f, 0.f, 0.f};
     WalkEstIn<3> west;
     if constexpr (WALK) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            xx[i] = P.st.ctrl[tt[i]];                 // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+            xx[i] = P.st.ctrl[(3 * k + i) * n + env]; // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
             wprev[i] = WK.S.prev_ctrl[tt[i]];         // previous_ctrl of the control cost (:260-262)
         }
         walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         if constexpr (WPE > 1) {       // two waves share the SIMD: read the task state again here (the other wave covers the latency)
 #pragma unroll                        // instead of carrying 21 values through the substep loop
             for (int i = 0; i < 3; ++i) {
-                const int t = (3 * k_e + i) * n + env_e;
+                const int t = env_e * 12 + 3 * k_e + i;
                 wprev[i] = WK.S.prev_ctrl[t]; wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t];
             }
             if (lead) win = walk_env_load(WK.S, n, env_e);

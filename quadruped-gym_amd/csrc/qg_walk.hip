@@ -27,17 +27,17 @@
 
 #include "qg_walk_dev.h"     // KWalkParams / KWalkState and the per-env device functions (shared with the fused step kernel)
 
-// one thread per (channel, env): thread t = channel * n + env
+// one thread per (env, channel): thread t = env * 12 + channel
 __global__ void qg_walk_pre_kernel(KWalkParams P, KWalkState S, int n, const float *__restrict__ actions, const float *__restrict__ data_ctrl,
                                    const int32_t *__restrict__ nstep) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 12 * n) return;
-    const int ch = t / n, env = t - ch * n;
+    const int env = t / 12, ch = t - env * 12;
     // effective action: the joint centres while the robot settles (walking_quad.py:142-143)
     const bool settle = nstep[env] < P.settle_substeps;
     S.eff_actions[(size_t)env * 12 + ch] = settle ? P.joint_centers[ch] : actions[(size_t)env * 12 + ch];
     const int tt[1] = {t};
-    const float xx[1] = {data_ctrl[t]};
+    const float xx[1] = {data_ctrl[ch * n + env]};     // data.ctrl is physics state: [12][n]
     const int calls = S.calls[env];
     WalkEstIn<1> in;
     float f_new[1], a_new[1];
@@ -57,7 +57,7 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
     for (int j = 0; j < 12; ++j) {
         float c = S.eff_actions[(size_t)env * 12 + j];               // data.ctrl after the step
         c = fminf(fmaxf(c, -1.f), 1.f);                              // quadruped.py:160
-        walk_channel_terms(P, S, n, env, j, c, S.prev_ctrl[j * n + env], S.f_est[j * n + env], S.a_est[j * n + env], sum);
+        walk_channel_terms(P, S, n, env, j, c, S.prev_ctrl[env * 12 + j], S.f_est[env * 12 + j], S.a_est[env * 12 + j], sum);
     }
     // the physics reset has already advanced the env's episode counter: the key of the episode that begins is episode - 1
     const WalkEnvIn in = walk_env_load(S, n, env);
@@ -79,6 +79,6 @@ __global__ void qg_walk_reset_kernel(KWalkParams P, KWalkState S, int n, const u
     if (env >= n) return;
     if (mask && !mask[env]) return;
     S.ideal[env] = 0.f; S.ideal[n + env] = 0.f;
-    for (int j = 0; j < 12; ++j) S.prev_ctrl[j * n + env] = P.joint_centers[j];
+    for (int j = 0; j < 12; ++j) S.prev_ctrl[env * 12 + j] = P.joint_centers[j];
     S.has_derive[env] = 0;
 }

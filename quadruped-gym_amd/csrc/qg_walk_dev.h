@@ -32,21 +32,21 @@ struct KWalkState {
     // commands (control_inputs.py): local velocity xy, heading unit vector xy, global velocity xy   [2][n] each
     float *vel, *head, *gvel;
     float *ideal;            // [2][n]   ideal position (integrated commanded global velocity)
-    float *prev_ctrl;        // [12][n]  walking_quad.py:260-262
+    float *prev_ctrl;        // [n][12]  walking_quad.py:260-262
     float *prev_ctrl_cost;   // [n]      set on the first step ever, never updated (:266-270)
     uint8_t *has_ctrl_cost;  // [n]
     float *prev_derive;      // [n]      previous_rewards_to_derive (:388-396)
     uint8_t *has_derive;     // [n]      cleared by every reset (:109)
     // estimator (math_utils.py): never reset between episodes (walking_quad.py:115)
     int32_t *calls;          // [n]      update() calls so far: buffer index = calls % window, samples = min(calls, window)
-    float *sig;              // [window][12][n]
-    float *bmax, *bmin;      // [blocks][12][n]  max / min of each 16-sample block of the ring buffer
-    float *omax, *omin;      // [12][n]  max / min over the filled blocks other than the one being written (cache, see walk_estimator_update_n)
-    uint8_t *cross;          // [window][12][n]
-    int32_t *count;          // [12][n]  running number of derivative sign changes inside the window
-    float *prev;             // [12][n]
-    float *sign;             // [12][n]  -1 / 0 / +1
-    float *f_est, *a_est;    // [12][n]
+    float *sig;              // [window][n][12]
+    float *bmax, *bmin;      // [blocks][n][12]  max / min of each 16-sample block of the ring buffer
+    float *omax, *omin;      // [n][12]  max / min over the filled blocks other than the one being written (cache, see walk_estimator_load_n)
+    uint8_t *cross;          // [window][n][12]
+    int32_t *count;          // [n][12]  running number of derivative sign changes inside the window
+    float *prev;             // [n][12]
+    float *sign;             // [n][12]  -1 / 0 / +1
+    float *f_est, *a_est;    // [n][12]
     float *eff_actions;      // [n][12]  the action actually applied (joint centres while settling)
 };
 
@@ -64,7 +64,10 @@ struct KWalkNone {};
 template <bool WALK> struct WalkArgT { typedef KWalkNone type; };
 template <> struct WalkArgT<true> { typedef KWalkLaunch type; };
 
-// ---- estimator update of NCH channels of one env with data.ctrl (math_utils.py:53-131); t[c] = channel * n + env ------------
+// ---- estimator update of NCH channels of one env with data.ctrl (math_utils.py:53-131); t[c] = env * 12 + channel ------------
+// Per-channel task state is laid out ENV-MAJOR, channel-minor ([n][12]; ring buffers [slot][n][12]): the 12 channels of an env --
+// and the 48 of the four envs a wave of the one-link-per-lane kernel carries -- are contiguous.  Channel-major ([12][n], round 1)
+// made that kernel touch 12 separate 64-byte lines per load, 16 bytes of each: 7.4 us of task layer per walking step.
 // The amplitude is max - min over a sliding window of W samples.  The ring buffer carries per-block (16 samples) max / min
 // summaries, and -- new in round 2 -- the max / min over all OTHER filled blocks is cached while the write index stays inside one
 // block (it only changes when the index enters a new block, every 16th call), so a call touches the 16 samples of the current
@@ -188,7 +191,7 @@ __device__ __forceinline__ void walk_channel_terms(const KWalkParams &P, const K
                                                    float prev_ctrl, float f_est, float a_est, WalkSums &a) {
     const float inv_nu = 1.f / 12.f;
     float dc = c - prev_ctrl;                                        // control_cost (:254-270)
-    S.prev_ctrl[j * n + env] = c;
+    S.prev_ctrl[env * 12 + j] = c;
     a.cost = fmaf(dc, dc, a.cost);
     float pj = (c - P.joint_centers[j]) * inv_nu;                    // :249-253
     a.posture = fmaf(pj, pj, a.posture);
@@ -307,7 +310,7 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
     S.ideal[n + env] = restart ? 0.f : ideal_y;
     if (restart) {
 #pragma unroll
-        for (int j = 0; j < 12; ++j) S.prev_ctrl[j * n + env] = P.joint_centers[j];
+        for (int j = 0; j < 12; ++j) S.prev_ctrl[env * 12 + j] = P.joint_centers[j];
         S.has_derive[env] = 0;
         if (sample_here) walk_sample_command(P, S, n, env, seed, env_index_base, episode_key);     // walking_quad.py:121-122
     }
