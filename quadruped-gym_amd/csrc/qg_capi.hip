@@ -286,7 +286,7 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         hipLaunchKernelGGL(qg_step_kernel_link<false>, dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, KWalkNone{});
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
-        if (pblocks > 256 && !getenv("QG_ONE_WAVE_WG"))
+        if (pblocks > 256)
             hipLaunchKernelGGL(qg_step_kernel_pair<4>, dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P);
         else
             hipLaunchKernelGGL(qg_step_kernel_pair<1>, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);

@@ -1190,10 +1190,6 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         // 18.57 instead of 18.36 us per launch at 4096 envs (same-box A/B of eight paddings).  Pinning the loop to a 64-byte
         // boundary makes its layout independent of what precedes it.
         asm volatile(".p2align 6");
-#ifdef QG_EXP_PAD
-#pragma unroll
-        for (int q = 0; q < QG_EXP_PAD; ++q) asm volatile("s_nop 0");
-#endif
 #pragma unroll 1
         for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
         if (!lag) {   // un-lagged sensors (task.sensor_lag = 0): one extra forward pass on a scratch copy of the state

@@ -1,0 +1,33 @@
+"""Time the partially observable walking env-step (POWalkingQuadrupedVecEnv.step_tensor: fused walking launch + observation-stack
+launch) with everything resident on the GPU.  usage: python tools/po_step_rate.py [n_envs] [obs_window] [steps]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+win = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+env = POWalkingQuadrupedVecEnv(n, obs_window=win, random_controls=True, random_init=True, device_commands=True,
+                               reset_options={"min_speed": 0.0, "max_speed": 0.5}, max_time=20.0, frame_skip=10)
+env.reset()
+dev = torch.device("cuda:0")
+acts = [torch.rand((n, 12), device=dev) * 2 - 1 for _ in range(8)]
+obs = torch.empty((n, env.obs_dim), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, device=dev, dtype=torch.uint8)
+for k in range(200):
+    env.step_tensor(acts[k % 8], obs, rew, done)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for k in range(steps):
+    env.step_tensor(acts[k % 8], obs, rew, done)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / steps * 1e3
+print(f"PO walking step (frame_skip 10, window {win}), {n} envs: {us:.2f} us per env-step = {n / us:.1f} M env-steps/s; finite {bool(torch.isfinite(obs).all())}")
+env.close()
