@@ -226,12 +226,20 @@ class QuadrupedVecEnv(_VecEnvBase):
     def _key(task):
         return bytes(task)
 
+    def _dict_key(self):
+        return (tuple(self.reward_fns.items()), tuple(self.termination_fns.items()), self.max_time, self.frame_skip)
+
     def _sync_task(self):
-        """Follow edits of the two dicts (README.md:74-89 assigns them after construction)."""
+        """Follow edits of the two dicts (README.md:74-89 assigns them after construction).  The common case -- nothing changed
+        since the last step -- costs two tuple comparisons."""
+        key = self._dict_key()
+        if key == getattr(self, "_dicts_seen", None):
+            return
         task, self._host_rewards, self._host_terms = self._plan()
         if self._key(task) != self._task_key:
             self._sim.set_task(task)
             self._task_key = self._key(task)
+        self._dicts_seen = key
 
     # -- SB3 VecEnv protocol ------------------------------------------------------------------------
     def reset(self):

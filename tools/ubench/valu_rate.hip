@@ -49,6 +49,21 @@ template <int MODE> __global__ __launch_bounds__(64) void k(float *out, float a,
             for (int r = 0; r < REP; r++)
 #pragma unroll
                 for (int i = 0; i < 8; i++) x[i] = __builtin_fmaf(x[i], x[(i + 1) & 7], x[(i + 2) & 7]);
+        } else if (MODE == 10) {  // 8 independent packed chains, VGPR-pair sources only (no SGPR / constant-bus operand)
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = __builtin_elementwise_fma(y[i], y[(i + 1) & 7], y[(i + 2) & 7]);
+        } else if (MODE == 11) {  // 8 independent packed multiplies by an SGPR pair
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = y[i] * a2;
+        } else if (MODE == 12) {  // 8 independent packed multiplies, VGPR pairs only
+#pragma unroll
+            for (int r = 0; r < REP; r++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = y[i] * y[(i + 1) & 7];
         } else if (MODE == 8) {   // dependent chain, VGPR sources only (no SGPR / constant-bus operand): x0 = fma(x0, x1, x2)
 #pragma unroll
             for (int r = 0; r < REP; r++)
@@ -90,6 +105,13 @@ template <int MODE> void run(const char *name, int waves_per_simd, float *d) {
 }
 int main() {
     float *d; hipMalloc(&d, 8192 * 64 * 4);
+    for (int w = 1; w <= 2; w++) {      // round 2: packed FP32 with and without a constant-bus operand
+        run<3>("v_pk_fma_f32 8 indep, SGPR pairs", w, d);
+        run<10>("v_pk_fma_f32 8 indep, VGPR only", w, d);
+        run<11>("v_pk_mul_f32 8 indep, SGPR pair", w, d);
+        run<12>("v_pk_mul_f32 8 indep, VGPR only", w, d);
+    }
+    if (getenv("QG_UBENCH_OCC"))
     for (int w = 1; w <= 8; w++) {      // round 2: does occupancy hide dependent-issue stalls when no SGPR operand is involved?
         if (w == 5 || w == 7) continue;
         run<8>("v_fma_f32 dependent, VGPR only", w, d);
