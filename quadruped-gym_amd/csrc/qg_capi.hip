@@ -44,6 +44,7 @@ struct qg_sim {
     int32_t mapping;          // QG_MAP_AUTO / QG_MAP_LANE / QG_MAP_QUAD (request)
     int32_t creating;
     int32_t walk_bound;       // qg_walk layers bound to this handle (qg_set_task refuses while > 0)
+    int32_t po_unfused;       // env QG_PO_UNFUSED=1: keep the observation pack of qg_po_step a launch of its own (A/B, parity test)
     int32_t quad_wpe;         // development override of the quad kernel's register cap (waves per SIMD), env QG_QUAD_WPE; 0 = policy
 };
 
@@ -141,6 +142,7 @@ extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *mode
     s->env_index_base = env_index_base;
     s->track_ctrl = 1;
     s->mapping = QG_MAP_AUTO;
+    if (const char *e = getenv("QG_PO_UNFUSED")) s->po_unfused = atoi(e) != 0;
     if (const char *e = getenv("QG_QUAD_WPE")) {
         int v = atoi(e);
         s->quad_wpe = (v >= 1 && v <= 4) ? v : 0;
@@ -246,8 +248,9 @@ static int effective_mapping(const qg_sim *s) {
 
 // `walk` != NULL: the fused walking launch (one-leg-per-lane kernel with the task layer folded in); walk_comps / walk_sample go
 // with it
+// `po` != NULL (with `walk`, one-link-per-lane mapping only): the partially observable observation pack fused in as well
 static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d_reward, uint8_t *d_done, float *d_comps,
-                       float *d_packed, hipStream_t stream, const KWalkLaunch *walk = nullptr) {
+                       float *d_packed, hipStream_t stream, const KWalkLaunch *walk = nullptr, const KPoLaunch *po = nullptr) {
     KStepArgs P;
     P.st = s->st;
     P.n = s->n;
@@ -262,10 +265,12 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.env_index_base = s->env_index_base;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     const int emap = effective_mapping(s);
+    if (po && !(walk && emap == QG_MAP_LINK)) return fail(QG_ERR_ARG, "launch_step: the fused observation pack needs the one-link-per-lane walking kernel");
     if (walk && emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
-        hipLaunchKernelGGL(qg_step_kernel_link<true>, dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, *walk);
+        if (po) hipLaunchKernelGGL((qg_step_kernel_link<true, true>), dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, *walk, *po);
+        else hipLaunchKernelGGL((qg_step_kernel_link<true, false>), dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, *walk, KPoNone{});
     } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
@@ -283,7 +288,7 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     } else if (emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
-        hipLaunchKernelGGL(qg_step_kernel_link<false>, dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, KWalkNone{});
+        hipLaunchKernelGGL((qg_step_kernel_link<false, false>), dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, KWalkNone{}, KPoNone{});
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         if (pblocks > 256)
@@ -789,7 +794,7 @@ extern "C" int qg_walk_reset(qg_walk *w, const uint8_t *mask, uint64_t seed, uin
 // pre + physics + post.  The commands of auto-reset envs are redrawn by the caller AFTER everything that still reads the old
 // ones (the partially observable pack) has been launched.
 static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *reward, uint8_t *done, float *components, void *stream,
-                          bool po_follows) {
+                          bool po_follows, const KPoLaunch *po_fused = nullptr) {
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     hipStream_t st = (hipStream_t)stream;
@@ -799,8 +804,9 @@ static int walk_step_core(qg_walk *w, const float *actions, float *obs, float *r
         wl.S = w->st;
         wl.comps = components;
         wl.sample = (w->kp.cmd_sample && !po_follows) ? 1 : 0;
-        return launch_step(s, actions, obs, reward, done, nullptr, nullptr, st, &wl);
+        return launch_step(s, actions, obs, reward, done, nullptr, nullptr, st, &wl, po_fused);
     }
+    if (po_fused) return fail(QG_ERR_ARG, "walk_step_core: no fused walking launch for this handle");
     int threads = 256;
     int total = 12 * s->n;
     hipLaunchKernelGGL(qg_walk_pre_kernel, dim3((total + threads - 1) / threads), dim3(threads), 0, st, w->kp, w->st, s->n, actions,
@@ -957,6 +963,17 @@ extern "C" int qg_po_step_device(qg_po *p, const float *actions, float *obs, flo
     if (!p || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_po_step_device: null argument");
     qg_walk *w = p->walk;
     qg_sim *s = w->sim;
+    // up to 4096 envs of the compiled-in robot the whole step -- physics, walking task layer, observation pack -- is ONE launch
+    // (QG_PO_UNFUSED=1 at qg_create keeps the separate observation-pack launch: the A/B and the parity test of the two forms)
+    if (walk_fused(s) && effective_mapping(s) == QG_MAP_LINK && !s->po_unfused) {
+        KPoLaunch pl;
+        pl.P = p->kp;
+        pl.S = p->st;
+        pl.out = obs;
+        pl.term_out = terminal_obs;
+        pl.sample = w->kp.cmd_sample ? 1 : 0;
+        return walk_step_core(w, actions, nullptr, reward, done, components, stream, true, &pl);
+    }
     int rc = walk_step_core(w, actions, p->d_obs33, reward, done, components, stream, true);
     if (rc != QG_OK) return rc;
     int blocks = (s->n + QG_PO_ENVS - 1) / QG_PO_ENVS;

@@ -19,6 +19,7 @@
 //     integration run redundantly in the 16 lanes; the three hinges of a leg are integrated redundantly in its four lanes.
 // Compiled-in robot only, lagged sensors only (the reference's), at most one wave per SIMD: the launcher uses it for n <= 4096.
 #define QGK_LINK_ENVS 4     // envs per wave
+#include "qg_po_dev.h"      // partially observable observation pack: per-env device functions of the fused <WALK, PO> variant
 
 template <int CTRL> DEV float dpp_any(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
@@ -288,9 +289,17 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
 // WALK: the walking task layer fused in as in qg_step_kernel_quad<.., WALK>, one control channel per lane: lane r < 3 of leg k owns
 // channel 3k + r (estimator update in the prologue, its terms of the reward sums in the epilogue), the env's lead lane evaluates
 // the reward.
-template <bool WALK = false>
+// PO (with WALK): the partially observable observation pack fused in as well (qg_po_dev.h) -- the whole POWalkingQuadrupedEnv.step
+// (po_walking_quad.py:29-57,71-90) is this one launch.  The workgroup's 16 envs x 16 lanes are exactly the stand-alone kernel's
+// layout (thread = 16 * local env + l16): the frames the new stack keeps are copied ring -> out in the prologue, the env's lead lane
+// runs the orientation filter on the step's sensors in the epilogue, the 16 lanes of the env write the new frame.  The 33 sensors
+// themselves are not written to memory at all.
+template <bool WALK = false, bool PO = false>
 __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_link(const KTask *__restrict__ T, KStepArgs P,
-                                                                                  const typename WalkArgT<WALK>::type WK) {
+                                                                                  const typename WalkArgT<WALK>::type WK,
+                                                                                  const typename PoArgT<PO>::type PK) {
+    static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
+    static_assert(QGK_LINK_ENVS * QGK_LINK_WAVES == QG_PO_ENVS && QGK_WAVE * QGK_LINK_WAVES == QG_PO_THREADS, "workgroup layout of qg_po_dev.h");
     __shared__ float tile_all[QGK_LINK_WAVES][QGK_LINK_ENVS * 35];
     const KModel &C = QG_BAKED_MODEL;
     // the task constants into scalar registers up front: read where they are used, every read in the epilogue was its own
@@ -361,6 +370,8 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         }
         if (lead_env) win = walk_env_load(WK.S, n, env);
     }
+    PoEnvIn pin = {};
+    if constexpr (PO) pin = po_env_load(PK.S, n, env);      // every lane of the env: the history copy below needs the ring position
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int j = 3 * k + i;
@@ -385,6 +396,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
             WK.S.eff_actions[(size_t)env * 12 + jch] = sel3(r, a_eff[0], a_eff[1], a_eff[2]);   // the action actually applied (the PO pack reads it)
         }
+    }
+    if constexpr (PO) {
+        int slot = pin.head + 1;
+        if (slot >= PK.P.window) slot = 0;
+        if (PK.P.window > 1) po_copy_history(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out);
     }
 
     float *srow = tile + el * 35;
@@ -417,8 +433,8 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
-    __syncthreads();
-    {
+    wave_sync();                                                    // the tile is this wave's own
+    if constexpr (!PO) {
         const int live_envs = max(0, min(QGK_LINK_ENVS, n - env0));     // a whole wave may lie past the last env
         const int total = live_envs * row;
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
@@ -464,6 +480,29 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         B.vw = v3(0.f, 0.f, 0.f);
         B.wb = v3(0.f, 0.f, 0.f);
         nstep = 0;
+    }
+    if constexpr (PO) {
+        __shared__ float s_new[QG_PO_ENVS][QG_PO_FRAME];     // the frame of this step
+        __shared__ float s_rst[QG_PO_ENVS][QG_PO_FRAME];     // the frame reset() would return (only for envs that finished)
+        __shared__ int s_slot[QG_PO_ENVS], s_fin[QG_PO_ENVS];
+        const int le = threadIdx.x >> 4;                     // = 4 * wave + el
+        if (live && lead_leg) {                              // data.ctrl of the frame: the env-clipped action this step applied
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_new[le][11 + 3 * k + i] = aclip[i];
+        }
+        if (live) {
+            // the heading of the command, which the env's lead lane holds, into lane 2 as well (it evaluates the angle)
+            const float hx = __shfl(win.hx, lane & ~15), hy = __shfl(win.hy, lane & ~15);
+            // an aliasing estimate shows data.qpos[3:7] as the step leaves it: B after the auto-reset above
+            po_frame_env16(PK.P, PK.S, n, env, lane & 15, lead_env, pin, srow, B.qw, B.qx, B.qy, B.qz, win.cvx, win.cvy, hx, hy, done,
+                           s_new[le], s_rst[le], &s_slot[le], &s_fin[le]);
+            // random_controls on the device: the new episode's command, drawn only now that both frames show the old one; the
+            // env's episode counter has not been advanced yet
+            if (lead_env && done && Tk.auto_reset && PK.sample)
+                walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, P.st.episode[env]);
+        }
+        wave_sync();                                         // the four envs of a wave are its own in every phase
+        po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
     }
     if (lead) {
         P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;

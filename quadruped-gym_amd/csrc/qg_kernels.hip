@@ -257,6 +257,15 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
 DEV float uniform24s(uint64_t seed, uint64_t env_index, uint64_t counter, uint32_t stream) {
     return uniform24(seed + 0xA0761D6478BD642Full * (uint64_t)stream, env_index, counter);
 }
+// Hand-off through LDS between the lanes of ONE wave (a tile no other wave touches): the wave's LDS operations execute in order, so
+// no s_barrier is needed -- in a four-wave workgroup that would also make every wave wait for the slowest of the four -- only the
+// compiler has to be told that other lanes read what this lane wrote.
+DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 #include "qg_walk_dev.h"     // walking task layer: per-env device functions used by the fused walking variant of the quad kernel
 
 // start value of hinge j at a reset with QG_RESET_JOINT_JITTER: qpos0 + jitter * U(-1, 1), kept inside the joint range
@@ -1261,7 +1270,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
-    __syncthreads();
+    wave_sync();                                                   // the tile is this wave's own
     {
         const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));      // a whole wave may lie past the last env
         const int total = live_envs * row;
@@ -1542,7 +1551,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
-    __syncthreads();
+    wave_sync();                                                   // the tile is this wave's own
     {
         const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));      // a whole wave may lie past the last env
         const int total = live_envs * row;

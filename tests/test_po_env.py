@@ -137,3 +137,42 @@ def test_po_step_tensor_equals_host_step():
         for i in np.nonzero(d)[0]:
             assert np.array_equal(infos[i]["terminal_observation"], term[i].cpu().numpy())
     a_env.close(); b_env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [1, 4, 10, 12])
+def test_po_fused_launch_equals_separate_launches(window, monkeypatch):
+    """Up to 4096 envs the whole partially observable step is ONE launch (physics + walking task layer + observation pack in
+    qg_step_kernel_link<WALK, PO>); QG_PO_UNFUSED=1 at construction keeps the observation pack a launch of its own.  Same
+    arithmetic, same order: physics, rewards, terminations and re-drawn commands must agree to the bit; the frames to the last bits
+    of the filter's Euler angles (the two kernels contract the same expressions into different FMAs)."""
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
+    n, fs = 40, 4                                                  # 2.5 workgroups of the fused kernel
+    kw = dict(obs_window=window, settling_time=0.05, frame_skip=fs, max_time=0.12, random_init=True, random_controls=True,
+              device_commands=True, seed=11, reset_options={"min_speed": 0.1, "max_speed": 0.4})
+    fused = POWalkingQuadrupedVecEnv(n, **kw)
+    monkeypatch.setenv("QG_PO_UNFUSED", "1")
+    split = POWalkingQuadrupedVecEnv(n, **kw)
+    monkeypatch.delenv("QG_PO_UNFUSED")
+    assert np.array_equal(fused.reset(), split.reset())
+    rng = np.random.default_rng(2)
+    finished, worst = 0, 0.0
+    for k in range(50):                                            # 15 env-steps per episode: three auto-resets per env
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        o1, r1, d1, i1 = fused.step(a)
+        o2, r2, d2, i2 = split.step(a)
+        assert np.array_equal(d1, d2), k
+        assert np.allclose(o1, o2, rtol=0, atol=5e-6), (k, np.abs(o1 - o2).max())
+        assert np.array_equal(r1, r2, equal_nan=True), k
+        for i in np.nonzero(d1)[0]:
+            assert np.allclose(i1[i]["terminal_observation"], i2[i]["terminal_observation"], rtol=0, atol=5e-6), (k, i)
+        finished += int(d1.sum())
+        worst = max(worst, float(np.abs(o1 - o2).max()))
+        (v1, h1), (v2, h2) = fused.commands(), split.commands()
+        assert np.array_equal(v1, v2) and np.array_equal(h1, h2), k
+    assert finished >= 2 * n
+    print(f"window {window}: largest frame difference fused vs separate {worst:.2e}")
+    s1, s2 = fused._sim.get_state(), split._sim.get_state()
+    for x, y in zip(s1, s2):
+        assert np.array_equal(x, y)
+    fused.close(); split.close()
