@@ -300,7 +300,9 @@ int qg_po_obs_dim(const qg_po *po);                                         /* 2
 /* POWalkingQuadrupedEnv.reset (:59-69); obs (nullable, host pointer [n][obs_dim]) receives the stacked reset frames */
 int qg_po_reset(qg_po *po, const uint8_t *mask, uint64_t seed, uint32_t flags, float *obs);
 /* POWalkingQuadrupedEnv.step (:72-90).  obs: [n][obs_dim]; terminal_obs: nullable, receives the last stacked
- * observation of envs that finished (rows of other envs are left untouched); components: [n][11], nullable. */
+ * observation of envs that finished (rows of other envs are left untouched); components: [n][11], nullable.
+ * Up to 4096 envs of the built-in robot the whole step is ONE kernel launch (physics, walking task layer,
+ * observation pack); `obs` must not alias `actions`: the rows are written from the first instructions of the launch on. */
 int qg_po_step(qg_po *po, const float *actions, float *obs, float *reward, uint8_t *done, float *components, float *terminal_obs);
 int qg_po_step_device(qg_po *po, const float *actions, float *obs, float *reward, uint8_t *done, float *components,
                       float *terminal_obs, void *stream);
