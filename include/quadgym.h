@@ -65,14 +65,14 @@ extern "C" {
 #define QG_OBS_IMU 1     /* jointpos 12 + accel 3 + gyro 3 + velocimeter 3 = 21 (BASELINE config 5) */
 
 /* work mappings of the step kernel (qg_set_mapping) */
-#define QG_MAP_AUTO 0    /* the measured optimum per size, for the compiled-in robot: LINK up to 4096 envs, QUAD up to 16384 and for
-                            32769..57343, PAIR for 16385..32768 and >= 57344; QUAD for any other model numbers */
+#define QG_MAP_AUTO 0    /* the measured optimum per size: LINK up to 4096 envs; above, for the compiled-in robot QUAD up to 16384 and
+                            for 32769..57343, PAIR for 16385..32768 and >= 57344; QUAD for any other model numbers */
 #define QG_MAP_LANE 1    /* one environment per wavefront lane (64 envs per wave), any model numbers */
 #define QG_MAP_QUAD 2    /* one leg per lane, four lanes per environment (16 envs per wave), any model numbers */
 #define QG_MAP_PAIR 3    /* two legs per lane as packed FP32 pairs, two lanes per environment (32 envs per wave);
                             compiled-in robot only: qg_set_mapping refuses it for other model numbers */
-#define QG_MAP_LINK 4    /* one link per lane, sixteen lanes per environment (4 envs per wave); compiled-in robot and the
-                            reference's lagged sensors only (otherwise the request falls back to QUAD) */
+#define QG_MAP_LINK 4    /* one link per lane, sixteen lanes per environment (4 envs per wave), any model numbers; the reference's
+                            lagged sensors only (otherwise the request falls back to QUAD) */
 
 /* qg_reset flags */
 #define QG_RESET_RANDOM_YAW 1u   /* walking_quad.py:68-75: qpos[3:7] = [cos a/2, 0, 0, sin a/2], a ~ U(0, 2 pi) */

@@ -238,10 +238,10 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
 static int effective_mapping(const qg_sim *s) {
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
     if (s->mapping == QG_MAP_PAIR) return s->baked ? QG_MAP_PAIR : QG_MAP_QUAD;
-    if (s->mapping == QG_MAP_LINK) return (s->baked && s->task.sensor_lag) ? QG_MAP_LINK : QG_MAP_QUAD;
+    if (s->mapping == QG_MAP_LINK) return s->task.sensor_lag ? QG_MAP_LINK : QG_MAP_QUAD;
     // up to 4096 envs (1024 waves of the one-link-per-lane kernel = one per SIMD): 14.1 against 18.2 us per launch at 4096 envs; above,
     // a second wave per SIMD doubles its time (21.9 us at 5120 envs) and the one-leg-per-lane kernel is ahead (profiles/r02/map_sweep.txt)
-    if (s->baked && s->task.sensor_lag && s->n <= 1024 * QGK_LINK_ENVS) return QG_MAP_LINK;
+    if (s->task.sensor_lag && s->n <= 1024 * QGK_LINK_ENVS) return QG_MAP_LINK;
     if (s->baked && s->n > 1024 * QGK_QUAD_ENVS && (s->n <= 1024 * QGK_PAIR_ENVS || s->n >= 1792 * QGK_PAIR_ENVS)) return QG_MAP_PAIR;
     return QG_MAP_QUAD;
 }
@@ -269,8 +269,11 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     if (walk && emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
-        if (po) hipLaunchKernelGGL((qg_step_kernel_link<true, true>), dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, *walk, *po);
-        else hipLaunchKernelGGL((qg_step_kernel_link<true, false>), dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, *walk, KPoNone{});
+        dim3 lg(lblocks), lb(QGK_WAVE * QGK_LINK_WAVES);
+        if (po && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, true, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+        else if (po) hipLaunchKernelGGL((qg_step_kernel_link<true, true, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+        else if (s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, false, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+        else hipLaunchKernelGGL((qg_step_kernel_link<true, false, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
     } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
@@ -288,7 +291,9 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     } else if (emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
-        hipLaunchKernelGGL((qg_step_kernel_link<false, false>), dim3(lblocks), dim3(QGK_WAVE * QGK_LINK_WAVES), 0, stream, s->d_task, P, KWalkNone{}, KPoNone{});
+        dim3 lg(lblocks), lb(QGK_WAVE * QGK_LINK_WAVES);
+        if (s->baked) hipLaunchKernelGGL((qg_step_kernel_link<false, false, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+        else hipLaunchKernelGGL((qg_step_kernel_link<false, false, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         if (pblocks > 256)
@@ -963,7 +968,7 @@ extern "C" int qg_po_step_device(qg_po *p, const float *actions, float *obs, flo
     if (!p || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_po_step_device: null argument");
     qg_walk *w = p->walk;
     qg_sim *s = w->sim;
-    // up to 4096 envs of the compiled-in robot the whole step -- physics, walking task layer, observation pack -- is ONE launch
+    // up to 4096 envs the whole step -- physics, walking task layer, observation pack -- is ONE launch
     // (QG_PO_UNFUSED=1 at qg_create keeps the separate observation-pack launch: the A/B and the parity test of the two forms)
     if (walk_fused(s) && effective_mapping(s) == QG_MAP_LINK && !s->po_unfused) {
         KPoLaunch pl;

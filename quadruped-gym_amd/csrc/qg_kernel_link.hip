@@ -17,7 +17,8 @@
 //   * the 33 base-block numbers (+ 4 of the FRAME contact) are summed over the env's 16 lanes with a symmetric DPP butterfly
 //     (quad_perm, quad_perm, row_half_mirror, row_mirror: every lane gets the bit-identical sum); base prelude, 6x6 solve and base
 //     integration run redundantly in the 16 lanes; the three hinges of a leg are integrated redundantly in its four lanes.
-// Compiled-in robot only, lagged sensors only (the reference's), at most one wave per SIMD: the launcher uses it for n <= 4096.
+// Lagged sensors only (the reference's), at most one wave per SIMD: the launcher uses it for n <= 4096.  Two variants as for the
+// one-leg-per-lane kernel: the compiled-in robot with literal constants, any other robot with the model tables staged in LDS.
 #define QGK_LINK_ENVS 4     // envs per wave
 #include "qg_po_dev.h"      // partially observable observation pack: per-env device functions of the fused <WALK, PO> variant
 
@@ -52,6 +53,9 @@ struct LegJoints { float q[3], qd[3], act[3], u[3], sc[6]; };
 
 DEV float sel3(int r, float a, float b, float c) { return r == 0 ? a : (r == 1 ? b : c); }
 
+// BAKED: the compiled-in robot, whose legs are quarter-turn copies of one another: the chain's constants are literals and the lane
+// works in its leg's quarter-turn frame (cm, sm).  Otherwise `C` is the model staged in LDS and the chain reads leg kleg's own links.
+template <bool BAKED>
 DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg, bool lead_env, BaseState &B, LegJoints &J, const LinkRegs &K,
                       bool want_sensors, float *__restrict__ row, int kleg, float &zaxis_z) {
     const float h = C.h;
@@ -71,7 +75,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
     }
     const int rr = r < 2 ? r : 2;                    // the spare lane shadows link 2 through the chain
     // ---- kinematic chain: lane r runs steps 0..r --------------------------------------------------------------------------
-    Fr Ep = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
+    Fr Ep = {v3(BAKED ? cm : 1.f, BAKED ? sm : 0.f, 0.f), v3(BAKED ? -sm : 0.f, BAKED ? cm : 1.f, 0.f), v3(0.f, 0.f, 1.f)};
     V3 pp = v3(0.f, 0.f, 0.f);
     SV vp = bc.V0, ap = bc.A0;
     // every lane computes every step (S[i] of a descendant is never read by an ancestor's lane); only the carry -- frame, origin,
@@ -79,7 +83,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
     SV S[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const KLink &L = C.link[i];
+        const KLink &L = link_of<BAKED>(C, kleg, i);
         const float sn = J.sc[2 * i], cs = J.sc[2 * i + 1];
         V3 p = pp + rot(Ep, ld3(L.pos));
         V3 tx = fma3(L.Q[0], Ep.ex, fma3(L.Q[3], Ep.ey, L.Q[6] * Ep.ez));
@@ -143,8 +147,12 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
         const float zbF = C.contact_margin - B.pw.z;
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
-            V3 r0 = ld3(C.cp0[4 * o]);
-            contact_point(v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z), nb, zbF, wsumF, sF);
+            if constexpr (BAKED) {
+                V3 r0 = ld3(C.cp0[4 * o]);
+                contact_point(v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z), nb, zbF, wsumF, sF);
+            } else {
+                contact_point(ld3(C.cp0[3 * kleg + o]), nb, zbF, wsumF, sF);   // any partition of the 12 points over the 4 spare lanes
+            }
         }
         const float mF = r == 3 ? 1.f : 0.f;
         wsumF *= mF; sF = mF * sF;
@@ -276,7 +284,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
             J.qd[i] = fmaf(h, qdd[i], J.qd[i]);
             J.q[i] = fmaf(h, J.qd[i], J.q[i]);
             hinge_advance(h * J.qd[i], J.sc[2 * i], J.sc[2 * i + 1]);
-            J.act[i] = fmaf(J.u[i] - J.act[i], C.link[i].act_decay, J.act[i]);
+            J.act[i] = fmaf(J.u[i] - J.act[i], link_of<BAKED>(C, kleg, i).act_decay, J.act[i]);
         }
     }
     base_integrate(bc, h, wdot, acl, B);
@@ -294,14 +302,21 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
 // layout (thread = 16 * local env + l16): the frames the new stack keeps are copied ring -> out in the prologue, the env's lead lane
 // runs the orientation filter on the step's sensors in the epilogue, the 16 lanes of the env write the new frame.  The 33 sensors
 // themselves are not written to memory at all.
-template <bool WALK = false, bool PO = false>
-__global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_link(const KTask *__restrict__ T, KStepArgs P,
+template <bool WALK = false, bool PO = false, bool BAKED = true>
+__global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_link(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
                                                                                   const typename WalkArgT<WALK>::type WK,
                                                                                   const typename PoArgT<PO>::type PK) {
     static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
     static_assert(QGK_LINK_ENVS * QGK_LINK_WAVES == QG_PO_ENVS && QGK_WAVE * QGK_LINK_WAVES == QG_PO_THREADS, "workgroup layout of qg_po_dev.h");
     __shared__ float tile_all[QGK_LINK_WAVES][QGK_LINK_ENVS * 35];
-    const KModel &C = QG_BAKED_MODEL;
+    __shared__ KModel smodel;
+    if constexpr (!BAKED) {                         // any other robot: the model tables staged in LDS, read with per-lane (leg) addresses
+        const float *src = reinterpret_cast<const float *>(Mp);
+        float *dst = reinterpret_cast<float *>(&smodel);
+        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * QGK_LINK_WAVES) dst[i] = src[i];
+        __syncthreads();
+    }
+    const KModel &C = BAKED ? QG_BAKED_MODEL : smodel;
     // the task constants into scalar registers up front: read where they are used, every read in the epilogue was its own
     // scalar-load round trip in front of a wave that has nothing else to do
     struct { int32_t frame_skip, limit_substeps, use_fall, use_flip, obs_mode, auto_reset; uint32_t reset_flags; float fall_height, w_forward, w_ctrl, alive_bonus;
@@ -328,8 +343,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     {
         const int rk = r < 2 ? r : 2;
         const KLink &L0 = C.link[0], &L1 = C.link[1], &L2 = C.link[2];
+        const KLink &Lown = C.link[3 * k + rk];     // !BAKED: this lane's own link, read from the staged table
         const float ml = r < 3 ? 1.f : 0.f;
-#define QG_SEL(field) sel3(rk, L0.field, L1.field, L2.field)
+#define QG_SEL(field) (BAKED ? sel3(rk, L0.field, L1.field, L2.field) : Lown.field)
         K.mass = ml * QG_SEL(mass);
 #pragma unroll
         for (int i = 0; i < 3; ++i) K.ipos[i] = QG_SEL(ipos[i]);
@@ -382,11 +398,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         }
         float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
         aclip[i] = a;
-        J.u[i] = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
+        J.u[i] = fminf(fmaxf(a, link_of<BAKED>(C, k, i).ctrl_lo), link_of<BAKED>(C, k, i).ctrl_hi);
         J.q[i] = P.st.qpos[(7 + j) * n + env];
         J.qd[i] = P.st.qvel[(6 + j) * n + env];
         J.act[i] = P.st.act[j * n + env];
-        sincos_f(J.q[i] - C.link[i].ref, J.sc[2 * i], J.sc[2 * i + 1]);
+        sincos_f(J.q[i] - link_of<BAKED>(C, k, i).ref, J.sc[2 * i], J.sc[2 * i + 1]);
     }
     if constexpr (WALK) {
         asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
@@ -408,7 +424,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     const int fs = Tk.frame_skip;
     asm volatile(".p2align 6");
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep_link(C, cm, sm, r, lead_leg, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
+    for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_leg, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
     int nstep = nstep0 + fs;
 
     float ssq = 0.f;
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int j = 3 * k + i;
-            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : J.q[i];
+            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : J.q[i];
             P.st.qvel[(6 + j) * n + env] = rst ? 0.f : J.qd[i];
             P.st.act[j * n + env] = rst ? 0.f : J.act[i];
             if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? Tk.default_ctrl[j] : aclip[i];

@@ -134,7 +134,7 @@ class BatchedSim:
 
     def set_mapping(self, mapping: int):
         """``_abi.MAP_AUTO`` / ``MAP_LANE`` (one env per lane) / ``MAP_QUAD`` (one leg per lane) / ``MAP_PAIR`` (two legs per
-        lane, packed f32; built-in robot only)."""
+        lane, packed f32; built-in robot only) / ``MAP_LINK`` (one link per lane; lagged sensors only)."""
         check(self._lib.qg_set_mapping(self._h, int(mapping)), "qg_set_mapping")
 
     @property

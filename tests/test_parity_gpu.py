@@ -133,7 +133,7 @@ def test_step_matches_oracle_on_fresh_states(oracle, mapping):
     sim.close()
 
 
-@pytest.mark.parametrize("mapping", ["lane", "quad"])
+@pytest.mark.parametrize("mapping", ["lane", "quad", "link"])
 def test_generic_variant_matches_oracle_on_a_modified_robot(oracle, mapping):
     """Any model other than the compiled-in default runs the generic kernel variant (tables read from
     device memory instead of literals).  Heavier feet, a different servo gain and a shifted hip mount
@@ -353,7 +353,7 @@ def test_diverged_envs_are_reported_done_and_reset(mapping):
 
 def test_auto_mapping_policy():
     """AUTO = the measured optimum per batch size (profiles/r01/pair_sweep.txt, profiles/r02/map_sweep.txt); a modified robot never
-    takes PAIR or LINK."""
+    takes PAIR; up to 4096 envs it runs the one-link-per-lane kernel with its tables in LDS."""
     from quadruped_gym_amd.sim import BatchedSim
     for n, want in ((64, _abi.MAP_LINK), (4096, _abi.MAP_LINK), (4097, _abi.MAP_QUAD), (16384, _abi.MAP_QUAD), (16385, _abi.MAP_PAIR),
                     (32768, _abi.MAP_PAIR), (32769, _abi.MAP_QUAD), (57343, _abi.MAP_QUAD), (57344, _abi.MAP_PAIR)):
@@ -370,6 +370,9 @@ def test_auto_mapping_policy():
     m = _abi.default_model()
     m.contact_friction = 0.7
     sim = BatchedSim(2048, model=m)
+    assert not sim.baked and sim.mapping == _abi.MAP_LINK
+    sim.close()
+    sim = BatchedSim(4097, model=m)
     assert not sim.baked and sim.mapping == _abi.MAP_QUAD
     sim.close()
     sim = BatchedSim(20000, model=m)

@@ -140,8 +140,8 @@ def test_po_step_tensor_equals_host_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", [1, 4, 10, 12])
-def test_po_fused_launch_equals_separate_launches(window, monkeypatch):
+@pytest.mark.parametrize("window,modified", [(1, False), (4, False), (10, False), (12, False), (10, True)])
+def test_po_fused_launch_equals_separate_launches(window, modified, monkeypatch):
     """Up to 4096 envs the whole partially observable step is ONE launch (physics + walking task layer + observation pack in
     qg_step_kernel_link<WALK, PO>); QG_PO_UNFUSED=1 at construction keeps the observation pack a launch of its own.  Same
     arithmetic, same order: physics, rewards, terminations and re-drawn commands must agree to the bit; the frames to the last bits
@@ -150,10 +150,22 @@ def test_po_fused_launch_equals_separate_launches(window, monkeypatch):
     n, fs = 40, 4                                                  # 2.5 workgroups of the fused kernel
     kw = dict(obs_window=window, settling_time=0.05, frame_skip=fs, max_time=0.12, random_init=True, random_controls=True,
               device_commands=True, seed=11, reset_options={"min_speed": 0.1, "max_speed": 0.4})
+    import quadruped_gym_amd.envs.walking as W
+    orig = W.load_model
+
+    def tweaked(path):                                             # a heavier, weaker robot: the kernel variant with tables in LDS
+        m, layout = orig(path)
+        for k in range(4):
+            m.body_mass[3 + 3 * k] *= 1.25
+            m.act_kp[1 + 3 * k] = 85.0
+        return m, layout
+    if modified:
+        monkeypatch.setattr(W, "load_model", tweaked)
     fused = POWalkingQuadrupedVecEnv(n, **kw)
     monkeypatch.setenv("QG_PO_UNFUSED", "1")
     split = POWalkingQuadrupedVecEnv(n, **kw)
     monkeypatch.delenv("QG_PO_UNFUSED")
+    assert fused._sim.baked == (not modified)
     assert np.array_equal(fused.reset(), split.reset())
     rng = np.random.default_rng(2)
     finished, worst = 0, 0.0

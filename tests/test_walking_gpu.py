@@ -205,9 +205,11 @@ def test_walk_destroy_restores_the_sim():
     sim.close()
 
 
-def test_fused_and_three_launch_walking_agree_on_a_modified_robot():
+@pytest.mark.parametrize("fused_mapping", ["auto", "quad"])
+def test_fused_and_three_launch_walking_agree_on_a_modified_robot(fused_mapping):
     """Any model other than the compiled-in one runs the table-driven kernel variants; the walking env-step is then the fused launch
-    of the generic one-leg-per-lane kernel (AUTO) or estimator -> generic one-env-per-lane kernel -> reward (LANE).  Same states,
+    of the generic one-link-per-lane kernel (AUTO up to 4096 envs) or one-leg-per-lane kernel (QUAD), or estimator -> generic
+    one-env-per-lane kernel -> reward (LANE).  Same states,
     same actions: rewards, components, estimates and dones must agree (the two differ only in the summation order of the four
     legs / twelve channels), across the settling phase, an estimator window wrap at frame_skip 20 and auto-resets."""
     from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
@@ -234,7 +236,10 @@ def test_fused_and_three_launch_walking_agree_on_a_modified_robot():
     finally:
         W.load_model = orig
     three._sim.set_mapping(_abi.MAP_LANE)
-    assert not fused._sim.baked and fused._sim.mapping == _abi.MAP_QUAD and three._sim.mapping == _abi.MAP_LANE
+    if fused_mapping == "quad":
+        fused._sim.set_mapping(_abi.MAP_QUAD)
+    want = _abi.MAP_LINK if fused_mapping == "auto" else _abi.MAP_QUAD
+    assert not fused._sim.baked and fused._sim.mapping == want and three._sim.mapping == _abi.MAP_LANE
     cmd_v = np.tile(np.array([[0.25, 0.05]], np.float32), (n, 1)); cmd_h = np.tile(np.array([[0.8, 0.6]], np.float32), (n, 1))
     for e in (fused, three):
         e.set_commands(cmd_v, cmd_h)
