@@ -271,7 +271,8 @@ def main():
                 gatherer.wait_buffer_free(compute)       # the gather that read packed[b] two steps ago
             if walk is not None:
                 check(lib.qg_walk_step_device(walk, pool[k & 15].data_ptr(), w_obs.data_ptr(), w_rew.data_ptr(), w_done.data_ptr(),
-                                              w_comp.data_ptr(), C.c_void_p(compute.cuda_stream)), "qg_walk_step_device")
+                                              None if os.environ.get("QG_BENCH_NO_COMPS") else w_comp.data_ptr(),
+                                              C.c_void_p(compute.cuda_stream)), "qg_walk_step_device")
                 continue
             step_fn(k & 15, b)
             if gatherer is not None:

@@ -274,6 +274,12 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         else if (po) hipLaunchKernelGGL((qg_step_kernel_link<true, true, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, *po);
         else if (s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, false, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         else hipLaunchKernelGGL((qg_step_kernel_link<true, false, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+    } else if (walk && emap == QG_MAP_PAIR) {
+        int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
+        if (pblocks > 256)
+            hipLaunchKernelGGL((qg_step_kernel_pair<4, true>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, *walk);
+        else
+            hipLaunchKernelGGL((qg_step_kernel_pair<1, true>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, *walk);
     } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
@@ -297,9 +303,9 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         if (pblocks > 256)
-            hipLaunchKernelGGL(qg_step_kernel_pair<4>, dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P);
+            hipLaunchKernelGGL((qg_step_kernel_pair<4, false>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, KWalkNone{});
         else
-            hipLaunchKernelGGL(qg_step_kernel_pair<1>, dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P);
+            hipLaunchKernelGGL((qg_step_kernel_pair<1, false>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, KWalkNone{});
     } else if (emap == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
@@ -582,7 +588,7 @@ struct qg_walk {
 // and 57 343; an explicit QUAD: always): 23.3 us against 33.0 us for estimator -> physics -> reward at 4096 envs.  Where AUTO takes
 // the two-legs-per-lane kernel (16 385 .. 32 768 envs, >= 57 344) the three launches around it stay ahead (46.6 us against 52.5 us
 // fused at 32 768 envs); LANE / PAIR requests keep the three launches too.
-static bool walk_fused(const qg_sim *s) { const int m = effective_mapping(s); return m == QG_MAP_QUAD || m == QG_MAP_LINK; }
+static bool walk_fused(const qg_sim *s) { const int m = effective_mapping(s); return m == QG_MAP_QUAD || m == QG_MAP_LINK || m == QG_MAP_PAIR; }
 
 extern "C" int qg_walk_default_params(qg_walk_params *p) {
     if (!p) return fail(QG_ERR_ARG, "qg_walk_default_params: null output");
@@ -641,6 +647,7 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     const double dt = s->model.timestep * s->task.frame_skip;        // walking_quad.py:56,93
     KWalkParams &k = w->kp;
     k.dt = (float)dt;
+    k.inv_dt = (float)(1.0 / dt);
     int64_t settle = params->settling_time > 0 ? qg_time_limit_substeps_impl(s->model.timestep, params->settling_time) : 0;
     k.settle_substeps = (int32_t)(settle > INT32_MAX ? INT32_MAX : settle);
     k.window = (int32_t)std::ceil(2.0 / (params->min_freq * dt));   // math_utils.py:26-28

@@ -373,18 +373,23 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     bool settle = false;
     int calls = 0;
     WalkEnvIn win = {};
+    WalkChanTargets wtg = {0.f, 0.f, 0.f};
     const int tt[1] = {env * 12 + jch};               // task state: [n][12]
     float xx[1] = {0.f}, wprev = 0.f, wf[1] = {0.f}, wa[1] = {0.f}, a_eff[3] = {0.f, 0.f, 0.f};
     WalkEstIn<1> west;
     if constexpr (WALK) {
         settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
         calls = WK.S.calls[env];
+        wtg = walk_channel_targets(WK.P, jch);
         if (r < 3) {
             xx[0] = P.st.ctrl[jch * n + env];         // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
             wprev = WK.S.prev_ctrl[tt[0]];            // previous_ctrl of the control cost (:260-262)
             walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west);
         }
-        if (lead_env) win = walk_env_load(WK.S, n, env);
+        if (lead_env) {
+            win = walk_env_load(WK.S, n, env);
+            win.episode_key = P.st.episode[env];      // not advanced yet: the key of the episode that begins if this one ends
+        }
     }
     PoEnvIn pin = {};
     if constexpr (PO) pin = po_env_load(PK.S, n, env);      // every lane of the env: the history copy below needs the ring position
@@ -470,13 +475,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     }
     if constexpr (WALK) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
-        if (wch) walk_channel_terms(WK.P, WK.S, n, env, jch, sel3(r, aclip[0], aclip[1], aclip[2]), wprev, wf[0], wa[0], sum);
+        if (wch) walk_channel_terms(WK.S, env, jch, wtg, sel3(r, aclip[0], aclip[1], aclip[2]), wprev, wf[0], wa[0], sum);
         sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
-        if (lead) {
-            // the env's episode counter has not been advanced yet: it is the key of the episode that begins if this one ends
-            walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base,
-                            P.st.episode[env]);
-        }
+        if (lead) walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
     }
     if (lead && P.comps) {
         P.comps[(size_t)env * 3 + 0] = c_fwd;
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             // random_controls on the device: the new episode's command, drawn only now that both frames show the old one; the
             // env's episode counter has not been advanced yet
             if (lead_env && done && Tk.auto_reset && PK.sample)
-                walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, P.st.episode[env]);
+                walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
         }
         wave_sync();                                         // the four envs of a wave are its own in every phase
         po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);

@@ -1135,6 +1135,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     const int tt[3] = {env * 12 + 3 * k + 0, env * 12 + 3 * k + 1, env * 12 + 3 * k + 2};     // task state: [n][12]
     float xx[3] = {0.f, 0.f, 0.f}, wprev[3] = {0.f, 0.f, 0.f}, wf[3] = {0.f, 0.f, 0.f}, wa[3] = {0.f, 0.f, 0.f}, a_eff[3] = {0.f, 0.f, 0.f};
     WalkEstIn<3> west;
+    WalkChanTargets wtg[3] = {};
     if constexpr (WALK) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -1143,7 +1144,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         }
         walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
         if constexpr (WPE == 1) {
-            if (k == 0) win = walk_env_load(WK.S, n, env);  // what the reward epilogue reads: fetched now, behind the physics
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wtg[i] = walk_channel_targets(WK.P, 3 * k + i);
+            if (k == 0) {                                   // what the reward epilogue reads: fetched now, behind the physics
+                win = walk_env_load(WK.S, n, env);
+                win.episode_key = P.st.episode[env];        // not advanced yet: the key of the episode that begins if this one ends
+            }
         }
     }
 #pragma unroll
@@ -1296,19 +1302,19 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             for (int i = 0; i < 3; ++i) {
                 const int t = env_e * 12 + 3 * k_e + i;
                 wprev[i] = WK.S.prev_ctrl[t]; wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t];
+                wtg[i] = walk_channel_targets(WK.P, 3 * k_e + i);
             }
-            if (lead) win = walk_env_load(WK.S, n, env_e);
+            if (lead) {
+                win = walk_env_load(WK.S, n, env_e);
+                win.episode_key = P.st.episode[env_e];
+            }
         }
         if (live) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) walk_channel_terms(WK.P, WK.S, n, env_e, 3 * k_e + i, aclip[i], wprev[i], wf[i], wa[i], sum);
+            for (int i = 0; i < 3; ++i) walk_channel_terms(WK.S, env_e, 3 * k_e + i, wtg[i], aclip[i], wprev[i], wf[i], wa[i], sum);
         }
         sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
-        if (lead) {
-            // the env's episode counter has not been advanced yet: it is the key of the episode that begins if this one ends
-            walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed,
-                            P.env_index_base, P.st.episode[env_e]);
-        }
+        if (lead) walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
     }
     if (lead && P.comps) {
         P.comps[(size_t)env_e * 3 + 0] = c_fwd;
@@ -1475,8 +1481,11 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
 // WAVES: waves per workgroup (1 or 4, one per SIMD of a CU; they do not interact).  A grid of 1024 one-wave workgroups costs ~1.6 us
 // more fixed time per launch than 256 four-wave ones (the dispatch of the workgroups themselves: tools/fs_sweep.sh on the
 // one-link-per-lane kernel), so grids of more than 256 waves are launched as four-wave workgroups.
-template <int WAVES>
-__global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P) {
+// WALK: the walking task layer fused in as in qg_step_kernel_quad<.., WALK>; the lane owns the six control channels of its two legs
+// (6 * half .. 6 * half + 5, contiguous in the env-major task state).
+template <int WAVES, bool WALK = false>
+__global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P,
+                                                                           const typename WalkArgT<WALK>::type WK) {
     __shared__ float tile_all[WAVES][QGK_PAIR_ENVS * 35];
     const KModel &C = QG_BAKED_MODEL;
     const int lane = threadIdx.x & (QGK_WAVE - 1);
@@ -1502,12 +1511,44 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     LegPair L;
     float aclip[6];
     float ssq = 0.f;
+    // WALK: every load of the task layer goes out among the state loads, every store of its prologue part after the last of them
+    // (see qg_step_kernel_quad)
+    bool settle = false;
+    int calls = 0;
+    WalkEnvIn win = {};
+    int tt[6] = {0, 0, 0, 0, 0, 0};
+    float xx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wprev[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+          wa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a_eff[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    WalkEstIn<6> west;
+    WalkChanTargets wtg[6] = {};
+    if constexpr (WALK) {
+        settle = nstep < WK.P.settle_substeps;                      // data.time < settling_time (walking_quad.py:142-143)
+        calls = WK.S.calls[env];
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) {
+            tt[c6] = env * 12 + 6 * half + c6;
+            xx[c6] = P.st.ctrl[(6 * half + c6) * n + env];           // data.ctrl of the PREVIOUS step (walking_quad.py:136)
+            wprev[c6] = WK.S.prev_ctrl[tt[c6]];                      // previous_ctrl of the control cost (:260-262)
+        }
+        walk_estimator_load_n<6>(WK.P, WK.S, n, tt, calls, west);
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) wtg[c6] = walk_channel_targets(WK.P, 6 * half + c6);
+        if (half == 0) {
+            win = walk_env_load(WK.S, n, env);
+            win.episode_key = P.st.episode[env];              // not advanced yet: the key of the episode that begins if this one ends
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int j = 3 * (2 * half + c) + i;
-            float a = fminf(fmaxf(P.actions[(size_t)env * 12 + j], -1.f), 1.f);    // quadruped.py:160
+            float a_in = P.actions[(size_t)env * 12 + j];
+            if constexpr (WALK) {
+                if (settle) a_in = WK.P.joint_centers[j];            // the joint centres while the robot settles
+                a_eff[3 * c + i] = a_in;
+            }
+            float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
             aclip[3 * c + i] = a;
             ssq = fmaf(a, a, ssq);
             float uu = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
@@ -1519,6 +1560,17 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     ssq = pair_sum(ssq);
 #pragma unroll
     for (int i = 0; i < 3; ++i) sincos_f(L.q[i] - f2(C.link[i].ref), L.sc[2 * i], L.sc[2 * i + 1]);
+    if constexpr (WALK) {
+        asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
+                     "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(L.q[0].x), "v"(L.q[1].x), "v"(L.q[2].x), "v"(L.q[0].y), "v"(L.q[1].y), "v"(L.q[2].y),
+                     "v"(L.qd[0].x), "v"(L.qd[1].x), "v"(L.qd[2].x), "v"(L.qd[0].y), "v"(L.qd[1].y), "v"(L.qd[2].y),
+                     "v"(L.act[0].x), "v"(L.act[1].x), "v"(L.act[2].x), "v"(L.act[0].y), "v"(L.act[1].y), "v"(L.act[2].y) : "memory");
+        if (live) {
+            walk_estimator_finish_n<6>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) WK.S.eff_actions[(size_t)env * 12 + 6 * half + c6] = a_eff[c6];
+        }
+    }
 
     float *srow = tile + el * 35;
     float zaxis_z = 1.f;
@@ -1567,8 +1619,17 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     }
     const bool lead = live && half == 0;
     if (lead && !P.packed) {
-        P.reward[env] = reward;
+        if constexpr (!WALK) P.reward[env] = reward;
         P.done[env] = done ? 1 : 0;
+    }
+    if constexpr (WALK) {
+        WalkSums sum = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) walk_channel_terms(WK.S, env, 6 * half + c6, wtg[c6], aclip[c6], wprev[c6], wf[c6], wa[c6], sum);
+        }
+        sum.cost = pair_sum(sum.cost); sum.posture = pair_sum(sum.posture); sum.amp = pair_sum(sum.amp); sum.frq = pair_sum(sum.frq);
+        if (lead) walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
     }
     if (lead && P.comps) {
         P.comps[(size_t)env * 3 + 0] = c_fwd;

@@ -57,11 +57,12 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
     for (int j = 0; j < 12; ++j) {
         float c = S.eff_actions[(size_t)env * 12 + j];               // data.ctrl after the step
         c = fminf(fmaxf(c, -1.f), 1.f);                              // quadruped.py:160
-        walk_channel_terms(P, S, n, env, j, c, S.prev_ctrl[env * 12 + j], S.f_est[env * 12 + j], S.a_est[env * 12 + j], sum);
+        walk_channel_terms(S, env, j, walk_channel_targets(P, j), c, S.prev_ctrl[env * 12 + j], S.f_est[env * 12 + j], S.a_est[env * 12 + j], sum);
     }
     // the physics reset has already advanced the env's episode counter: the key of the episode that begins is episode - 1
-    const WalkEnvIn in = walk_env_load(S, n, env);
-    walk_reward_env(P, S, n, env, obs + (size_t)env * 33, sum, in, done[env] != 0, reward, comps, sample_here, seed, env_index_base, episode[env] - 1);
+    WalkEnvIn in = walk_env_load(S, n, env);
+    in.episode_key = episode[env] - 1;
+    walk_reward_env(P, S, n, env, obs + (size_t)env * 33, sum, in, done[env] != 0, reward, comps, sample_here, seed, env_index_base);
 }
 
 // the same draw for the envs `select` marks (NULL = all), as its own launch: explicit resets

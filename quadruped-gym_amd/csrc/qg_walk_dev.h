@@ -9,8 +9,15 @@
 
 #define QG_WALK_BLOCK 16      // samples per block summary of the estimator's ring buffer
 
+// Square roots and reciprocals of the task layer: the hardware instructions (1 ulp), not the IEEE-exact expansions (~10 instructions
+// and an SGPR pair each -- on the one lane per env that evaluates the reward while its wave is alone on the SIMD).  The quantities
+// are O(1) sums of squares and durations; the parity bounds against the f64 oracle are four orders of magnitude wider.
+__device__ __forceinline__ float walk_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float walk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 struct KWalkParams {
     float dt;                    // timestep * frame_skip
+    float inv_dt;                // 1 / dt, rounded from double
     int32_t settle_substeps;     // data.time < settling_time  <=>  nstep < settle_substeps (f64-accumulated clock)
     int32_t window;              // estimator window size
     float ema_alpha;
@@ -160,7 +167,7 @@ __device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, co
         const int crossing = (have_sign && cur != in.psign[c]) ? 1 : 0;
         const int count = in.cnt[c] - in.cr[c] + crossing;                      // :94-96
         const float dur = (float)samples * P.dt;        // :109
-        const float f_cur = (0.5f * (float)count) / dur;                        // :113-114
+        const float f_cur = (0.5f * (float)count) * walk_rcp(dur);              // :113-114
         float mx = x[c], mn = x[c];
 #pragma unroll
         for (int j = 0; j < QG_WALK_BLOCK; ++j) {
@@ -187,17 +194,25 @@ __device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, co
 
 // ---- per-channel contributions to the reward sums; also moves previous_ctrl on (walking_quad.py:249-285) ------------------
 struct WalkSums { float cost, posture, amp, frq; };
-__device__ __forceinline__ void walk_channel_terms(const KWalkParams &P, const KWalkState &S, int n, int env, int j, float c /* data.ctrl, clipped */,
+// the three per-channel targets.  A channel index that differs from lane to lane makes these vector loads from the kernel-argument
+// segment: fetch them up front (in the fused kernels: in the prologue) -- read where they are used, in the epilogue of a wave that
+// is alone on its SIMD, each sat behind every store issued before it (vmcnt counts in order): three exposed round trips.
+struct WalkChanTargets { float center, amp, frq; };
+__device__ __forceinline__ WalkChanTargets walk_channel_targets(const KWalkParams &P, int j) {
+    WalkChanTargets t = {P.joint_centers[j], P.amp_target[j], P.freq_target[j]};
+    return t;
+}
+__device__ __forceinline__ void walk_channel_terms(const KWalkState &S, int env, int j, const WalkChanTargets &T, float c /* data.ctrl, clipped */,
                                                    float prev_ctrl, float f_est, float a_est, WalkSums &a) {
     const float inv_nu = 1.f / 12.f;
     float dc = c - prev_ctrl;                                        // control_cost (:254-270)
     S.prev_ctrl[env * 12 + j] = c;
     a.cost = fmaf(dc, dc, a.cost);
-    float pj = (c - P.joint_centers[j]) * inv_nu;                    // :249-253
+    float pj = (c - T.center) * inv_nu;                              // :249-253
     a.posture = fmaf(pj, pj, a.posture);
-    float aj = (a_est - P.amp_target[j]) * inv_nu;                   // :279-285
+    float aj = (a_est - T.amp) * inv_nu;                             // :279-285
     a.amp = fmaf(aj, aj, a.amp);
-    float fj = (f_est - P.freq_target[j]) * inv_nu;                  // :272-277
+    float fj = (f_est - T.frq) * inv_nu;                             // :272-277
     a.frq = fmaf(fj, fj, a.frq);
 }
 
@@ -226,9 +241,13 @@ __device__ __forceinline__ void walk_sample_command(const KWalkParams &P, const 
 struct WalkEnvIn {
     float cvx, cvy, hx, hy, gvx, gvy, ideal_x, ideal_y, first_cost, prev_derive;
     int has_cost, has_derive;
+    int calls;               // update() calls of the estimator before this step
+    int episode_key;         // counter of the episode that begins if this one ends (the caller fills it in: it lives in the simulator's state)
 };
 __device__ __forceinline__ WalkEnvIn walk_env_load(const KWalkState &S, int n, int env) {
     WalkEnvIn in;
+    in.calls = S.calls[env];
+    in.episode_key = 0;
     in.cvx = S.vel[env]; in.cvy = S.vel[n + env];
     in.hx = S.head[env]; in.hy = S.head[n + env];
     in.gvx = S.gvel[env]; in.gvy = S.gvel[n + env];
@@ -247,7 +266,7 @@ __device__ __forceinline__ WalkEnvIn walk_env_load(const KWalkState &S, int n, i
 __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWalkState &S, int n, int env, const float *s, const WalkSums &sum,
                                                 const WalkEnvIn &in, bool finished, float *__restrict__ reward,
                                                 float *__restrict__ comps /* [n][11] or NULL */, int sample_here, uint64_t seed,
-                                                uint64_t env_index_base, int episode_key) {
+                                                uint64_t env_index_base) {
     const float px = s[18], py = s[19], pz = s[20];                  // body_pos
     const float xax = s[24], xay = s[25];                            // body_xaxis
     const float zaz = s[29];                                         // body_zaxis z
@@ -267,10 +286,10 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
     // (math_utils.py:7-8) and that NaN reaches the direction term and the total.  The device pass is compiled with
     // -ffinite-math-only, under which 0/0 is formally undefined, so the documented NaN is produced explicitly: the
     // division is guarded and the quiet-NaN bit pattern is stored through integer selects below.
-    const float nv = __builtin_sqrtf(vx * vx + vy * vy), nc = __builtin_sqrtf(cvx * cvx + cvy * cvy);
+    const float nv = walk_sqrt(vx * vx + vy * vy), nc = walk_sqrt(cvx * cvx + cvy * cvy);
     const bool degenerate = (nv == 0.f) || (nc == 0.f);
     const float dv = degenerate ? 1.f : nv, dc = degenerate ? 1.f : nc;
-    const float direction = (vx / dv) * (cvx / dc) + (vy / dv) * (cvy / dc);
+    const float direction = (vx * cvx + vy * cvy) * walk_rcp(dv * dc);   // = unit(v) . unit(c): one reciprocal instead of four divisions
     const float dsp = nv - nc;
     const float speed_cost = dsp * dsp;
     const float heading = xax * hx + xay * hy;                       // :231-235
@@ -283,14 +302,14 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
     v[4] = P.w[4] * (__expf(heading) - 1.f);                          // exp_dist, math_utils.py:4-5
     v[5] = P.w[5] * (__expf(zaz) - 1.f);
     v[6] = P.w[6] * (__expf(height) - 1.f);
-    v[7] = P.w[7] * __builtin_sqrtf(sum.posture);
-    v[8] = P.w[8] * __builtin_sqrtf(sum.amp);
-    v[9] = P.w[9] * __builtin_sqrtf(sum.frq);
+    v[7] = P.w[7] * walk_sqrt(sum.posture);
+    v[8] = P.w[8] * walk_sqrt(sum.amp);
+    v[9] = P.w[9] * walk_sqrt(sum.frq);
     // derived term (:383-396): d/dt of -20 * |pos_xy - ideal_xy|, zero on the first step after a reset
     const float ex = px - ideal_x, ey = py - ideal_y;
-    const float derive = P.w_diff_ideal * __builtin_sqrtf(ex * ex + ey * ey);
+    const float derive = P.w_diff_ideal * walk_sqrt(ex * ex + ey * ey);
     const float prev = in.has_derive ? in.prev_derive : derive;
-    v[10] = (derive - prev) / P.dt;
+    v[10] = (derive - prev) * P.inv_dt;
     S.prev_derive[env] = derive;
     S.has_derive[env] = 1;
     float total = 0.f;
@@ -303,7 +322,7 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
 #pragma unroll
         for (int k = 0; k < 11; ++k) cu[k] = (k == 2 && degenerate) ? qnan : __builtin_bit_cast(unsigned, v[k]);
     }
-    S.calls[env] += 1;                                                // the estimator update of this step is complete
+    S.calls[env] = in.calls + 1;                                      // the estimator update of this step is complete
     // episode bookkeeping of envs the physics has just auto-reset (walking_quad.py:96-126)
     const bool restart = P.auto_reset && finished;
     S.ideal[env] = restart ? 0.f : ideal_x;
@@ -312,6 +331,6 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
 #pragma unroll
         for (int j = 0; j < 12; ++j) S.prev_ctrl[env * 12 + j] = P.joint_centers[j];
         S.has_derive[env] = 0;
-        if (sample_here) walk_sample_command(P, S, n, env, seed, env_index_base, episode_key);     // walking_quad.py:121-122
+        if (sample_here) walk_sample_command(P, S, n, env, seed, env_index_base, in.episode_key);  // walking_quad.py:121-122
     }
 }
