@@ -199,6 +199,9 @@ int qg_get_task(const qg_sim *sim, qg_task *out);
 /* data.ctrl (the last env-clipped action, quadruped.py:164) is written back each step only
  * while this is on (default on; bulk-throughput callers switch it off). */
 int qg_set_track_ctrl(qg_sim *sim, int32_t on);
+/* Development builds only (make CXXFLAGS+=-DQG_PHASE_TIMES; tools/phase_times.py): the 100 MHz clock stamps the first wave of the last
+ * one-link-per-lane launch took at its phase marks.  Production builds carry no such code and return QG_ERR_ARG. */
+int qg_debug_phase_times(uint64_t out[16]);
 
 /* 1 when the handle's model equals the compiled-in default (include/qg_model_data.h) and the
  * kernel variant with those constants baked into the instruction stream runs; 0 for any other

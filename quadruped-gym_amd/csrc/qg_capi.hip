@@ -468,6 +468,19 @@ extern "C" int qg_get_task(const qg_sim *s, qg_task *out) {
     return QG_OK;
 }
 
+/* development builds (-DQG_PHASE_TIMES): the s_memrealtime stamps (10 ns units) of the last launch's first wave; QG_ERR_ARG in production builds */
+extern "C" int qg_debug_phase_times(uint64_t out[16]) {
+#ifdef QG_PHASE_TIMES
+    if (!out) return fail(QG_ERR_ARG, "qg_debug_phase_times: null output");
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(qg_phase_times), 16 * sizeof(uint64_t)), QG_ERR_DEVICE);
+    return QG_OK;
+#else
+    (void)out;
+    return fail(QG_ERR_ARG, "qg_debug_phase_times: the library was built without -DQG_PHASE_TIMES");
+#endif
+}
+
 extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     s->track_ctrl = on ? 1 : 0;

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     struct { int32_t frame_skip, limit_substeps, use_fall, use_flip, obs_mode, auto_reset; uint32_t reset_flags; float fall_height, w_forward, w_ctrl, alive_bonus;
              const float *default_ctrl; } Tk = {T->frame_skip, T->limit_substeps, T->use_fall, T->use_flip, T->obs_mode, T->auto_reset, T->reset_flags,
                                                T->fall_height, T->w_forward, T->w_ctrl, T->alive_bonus, T->default_ctrl};
+    QG_MARK(0);
     const int lane = threadIdx.x & (QGK_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     float *tile = tile_all[wave];
@@ -427,10 +428,16 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     float *srow = tile + el * 35;
     float zaxis_z = 1.f;
     const int fs = Tk.frame_skip;
+#ifdef QG_PHASE_TIMES
+    asm volatile("" :: "v"(B.pw.x), "v"(B.qw), "v"(B.vw.x), "v"(B.wb.x), "v"(J.q[0]), "v"(J.q[1]), "v"(J.q[2]), "v"(J.qd[0]), "v"(J.qd[1]), "v"(J.qd[2]),
+                 "v"(J.act[0]), "v"(J.act[1]), "v"(J.act[2]), "v"(J.sc[0]), "v"(J.sc[2]), "v"(J.sc[4]));
+#endif
+    QG_MARK(1);                                      // state in registers, prologue stores issued
     asm volatile(".p2align 6");
 #pragma unroll 1
     for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_leg, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
     int nstep = nstep0 + fs;
+    QG_MARK(2);                                      // physics done
 
     float ssq = 0.f;
 #pragma unroll
@@ -468,6 +475,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             }
         }
     }
+    QG_MARK(3);                                      // obs tile written out
     const bool lead = live && lead_env;
     if (lead && !P.packed) {
         if constexpr (!WALK) P.reward[env] = reward;
@@ -477,7 +485,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
         if (wch) walk_channel_terms(WK.S, env, jch, wtg, sel3(r, aclip[0], aclip[1], aclip[2]), wprev, wf[0], wa[0], sum);
         sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
+        QG_MARK(4);                                  // channel terms + sums
         if (lead) walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
+        QG_MARK(5);                                  // reward
     }
     if (lead && P.comps) {
         P.comps[(size_t)env * 3 + 0] = c_fwd;
@@ -498,6 +508,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         B.wb = v3(0.f, 0.f, 0.f);
         nstep = 0;
     }
+    QG_MARK(6);
     if constexpr (PO) {
         __shared__ float s_new[QG_PO_ENVS][QG_PO_FRAME];     // the frame of this step
         __shared__ float s_rst[QG_PO_ENVS][QG_PO_FRAME];     // the frame reset() would return (only for envs that finished)
@@ -519,8 +530,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
                 walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
         }
         wave_sync();                                         // the four envs of a wave are its own in every phase
+        QG_MARK(7);                                  // frame built
         po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
     }
+    QG_MARK(8);
     if (lead) {
         P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
         P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
@@ -539,4 +552,5 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? Tk.default_ctrl[j] : aclip[i];
         }
     }
+    QG_MARK(9);                                      // every store issued
 }

@@ -257,6 +257,16 @@ DEV float uniform24(uint64_t seed, uint64_t env_index, uint64_t counter) {
 DEV float uniform24s(uint64_t seed, uint64_t env_index, uint64_t counter, uint32_t stream) {
     return uniform24(seed + 0xA0761D6478BD642Full * (uint64_t)stream, env_index, counter);
 }
+// In-kernel phase clock (development builds only: -DQG_PHASE_TIMES, tools/phase_times.sh).  Wave 0 of workgroup 0 stamps
+// s_memrealtime (100 MHz) at the marks below into qg_phase_times[]; qg_debug_phase_times() copies them out and tools/phase_times.py
+// prints the deltas.  Compiled out otherwise: the production kernels carry none of it.
+#ifdef QG_PHASE_TIMES
+__device__ unsigned long long qg_phase_times[16];
+#define QG_MARK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { __builtin_amdgcn_sched_barrier(0); qg_phase_times[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define QG_MARK(i) do { } while (0)
+#endif
+
 // Hand-off through LDS between the lanes of ONE wave (a tile no other wave touches): the wave's LDS operations execute in order, so
 // no s_barrier is needed -- in a four-wave workgroup that would also make every wave wait for the slowest of the four -- only the
 // compiler has to be told that other lanes read what this lane wrote.
@@ -1487,6 +1497,7 @@ template <int WAVES, bool WALK = false>
 __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P,
                                                                            const typename WalkArgT<WALK>::type WK) {
     __shared__ float tile_all[WAVES][QGK_PAIR_ENVS * 35];
+    QG_MARK(0);
     const KModel &C = QG_BAKED_MODEL;
     const int lane = threadIdx.x & (QGK_WAVE - 1);
     const int wave = threadIdx.x >> 6;
@@ -1576,9 +1587,11 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     float zaxis_z = 1.f;
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
+    QG_MARK(1);                                      // state in registers, prologue stores issued
 #pragma unroll 1
     for (int s = 0; s < fs; ++s) substep_pair(C, cm, sm, B, L, lag && (s == fs - 1), srow, half, zaxis_z);
     nstep += fs;
+    QG_MARK(2);                                      // physics done
     if (!lag) {
         BaseState B2 = B;
         LegPair L2 = L;
@@ -1617,6 +1630,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
             }
         }
     }
+    QG_MARK(3);                                      // obs tile written out
     const bool lead = live && half == 0;
     if (lead && !P.packed) {
         if constexpr (!WALK) P.reward[env] = reward;
@@ -1629,7 +1643,9 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
             for (int c6 = 0; c6 < 6; ++c6) walk_channel_terms(WK.S, env, 6 * half + c6, wtg[c6], aclip[c6], wprev[c6], wf[c6], wa[c6], sum);
         }
         sum.cost = pair_sum(sum.cost); sum.posture = pair_sum(sum.posture); sum.amp = pair_sum(sum.amp); sum.frq = pair_sum(sum.frq);
+        QG_MARK(4);                                  // channel terms + sums
         if (lead) walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
+        QG_MARK(5);                                  // reward
     }
     if (lead && P.comps) {
         P.comps[(size_t)env * 3 + 0] = c_fwd;
