@@ -17,5 +17,8 @@ tools/profile_gpu.sh r02_quad_n4096 --mapping quad
 tools/profile_gpu.sh r02_pair_n32768_yaw --envs-per-gpu 32768 --random-yaw
 tools/profile_gpu.sh r02_link_n4096_fs20_imu --frame-skip 20 --obs-mode 1
 tools/profile_gpu.sh r02_walking_n4096 --walking
+python bench.py --generic-model --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/r02/bench_generic_model.json 2>/dev/null; echo "generic rc=$?"
+python tools/po_step_rate.py 4096 10 2000 > gpurun_out/r02/po_step_rate.txt 2>&1
+QG_PO_UNFUSED=1 python tools/po_step_rate.py 4096 10 2000 >> gpurun_out/r02/po_step_rate.txt 2>&1
 python tools/parity_report.py 4096 > gpurun_out/r02/parity_report.txt 2>&1; echo "parity rc=$?"
 python tools/rollout_demo.py > gpurun_out/r02/rollout_demo.txt 2>&1
