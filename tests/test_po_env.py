@@ -140,7 +140,7 @@ def test_po_step_tensor_equals_host_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window,modified", [(1, False), (4, False), (10, False), (12, False), (10, True)])
+@pytest.mark.parametrize("window,modified", [(1, False), (4, False), (10, False), (12, False), (64, False), (10, True)])
 def test_po_fused_launch_equals_separate_launches(window, modified, monkeypatch):
     """Up to 4096 envs the whole partially observable step is ONE launch (physics + walking task layer + observation pack in
     qg_step_kernel_link<WALK, PO>); QG_PO_UNFUSED=1 at construction keeps the observation pack a launch of its own.  Same
