@@ -87,3 +87,12 @@ def test_create_rejects_bad_arguments():
     t = _abi.default_task()
     t.frame_skip = 0
     assert lib.qg_create(4, 0, None, C.byref(t), 0, C.byref(h)) == -1
+
+
+def test_production_build_carries_no_phase_clock():
+    """qg_debug_phase_times only answers in a development build (-DQG_PHASE_TIMES, tools/phase_times.sh): the library the tests and
+    bench.py load must be the production one, whose kernels contain none of the timing marks."""
+    lib = _abi.load_library()
+    out = (C.c_uint64 * 16)()
+    assert lib.qg_debug_phase_times(out) == -1         # QG_ERR_ARG
+    assert b"QG_PHASE_TIMES" in lib.qg_last_error()
