@@ -479,13 +479,15 @@ def main():
     line = make_line(dt, kernel_ms, exchange_mode)
 
     # ---- multi-GPU, --exchange auto: the same K steps again as hipGraph replays, guarded by a watchdog -------------------------
-    # The eager loop is bound by the host's cost of issuing one collective per step (~36 us against an 18 us kernel); a graph of
-    # 8 env-steps has no per-step host work.  Graph replay of RCCL collectives across ranks cannot be validated on a one-GPU box,
+    # The eager loop is bound by the host's cost of issuing one collective per step (29-39 us against a 14 us kernel); a graph of
+    # 8 env-steps has no per-step host work.  (The same exchange from the library's C loop, --native-rccl, measured 32-36 us per step
+    # with a 1-rank group: the cost is RCCL's own enqueue, not Python -- so it is not part of the automatic attempts.)  Graph replay of RCCL collectives across ranks cannot be validated on a one-GPU box,
     # so the eager measurement above is ALWAYS taken first and is what gets printed if the attempt raises, stalls or is slower.
     try_graph = (use_dist and native is None and walk is None and state["graph"] is None and args.exchange == "auto"
                  and not args.rehearse_shared_gpu and not args.sync_gather and args.gather_op == "gather")
     fault = os.environ.get("QG_BENCH_GRAPH_FAULT")     # test hook: "raise" / "stall" exercise the two fallbacks of the attempt
-    G = 8 if args.steps % 8 == 0 else (4 if args.steps % 4 == 0 else (2 if args.steps % 2 == 0 else 0))
+    # env-steps per graph: the largest even divisor of K up to 16 (whole double-buffer cycles; a replay costs ~10 us of launch whatever it holds)
+    G = max([g for g in range(2, 17, 2) if args.steps % g == 0], default=0)
     if try_graph and G:
         import threading
 
@@ -534,6 +536,9 @@ def main():
         agreed = all_ok(ok) if captured else False
         watchdog.cancel()
         plausible = ok == 1 and dt_g / args.steps * 1e3 >= 0.9 * kernel_ms     # a step cannot take less than its own kernel
+        tried = {"eager (one torch.distributed gather per step)": round(dt / args.steps * 1e6, 2)}      # us per step of every loop that completed
+        if agreed and ok == 1:
+            tried[f"hipGraph replay of {G} env-steps"] = round(dt_g / args.steps * 1e6, 2)
         if agreed and not plausible:
             note = f"hipGraph replay timed an implausible {dt_g / args.steps * 1e6:.1f} us per step (kernel alone: {kernel_ms * 1e3:.1f} us): discarded"
         if agreed and plausible and dt_g < dt:
@@ -543,6 +548,8 @@ def main():
             line["graph_stalled"] = False
             line["config"]["exchange_note"] = (note or ("hipGraph attempt failed on another rank" if not agreed else
                                                         f"hipGraph replay measured slower ({dt_g / args.steps * 1e6:.1f} us per step)"))
+    if try_graph and G:
+        line["config"]["exchange_us_per_step"] = tried
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)

@@ -115,7 +115,8 @@ def test_exchange_auto_reports_a_valid_line_whatever_the_graph_attempt_does(faul
     assert CONTRACT_KEYS <= set(d) and d["steps"] == 400 and d["n_gpus"] == 1
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     if fault is None:
-        assert d["config"]["exchange"].startswith("hipGraph replay of 8 env-steps") and d["ms_per_step"] < 0.03
+        assert d["config"]["exchange"].startswith("hipGraph replay of 16 env-steps") and d["ms_per_step"] < 0.03
+        assert len(d["config"]["exchange_us_per_step"]) == 2             # both loops completed and are on record
     else:
         assert d["config"]["exchange"] == "eager" and "exchange_note" in d["config"]
         assert ("injected" in d["config"]["exchange_note"]) == (fault == "raise")
