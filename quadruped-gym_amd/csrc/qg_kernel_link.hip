@@ -457,6 +457,40 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     const int od = Tk.obs_mode == 1 ? 21 : 33;
     const int row = P.packed ? od + 2 : od;
     if (Tk.use_flip) done = done || (zaxis_z < 0.f);              // walking_quad.py:156-160, on the step's sensordata
+    // The state goes out FIRST (two dozen of the launch's ~30 store instructions): it drains while the rest of the epilogue computes.
+    const bool lead = live && lead_env;
+    const bool rst = done && Tk.auto_reset;
+    if (rst) {
+        B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+        B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+        if (Tk.reset_flags & 1u) {
+            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
+            float sn, cs;
+            sincos_f(0.5f * a, sn, cs);
+            B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+        }
+        B.vw = v3(0.f, 0.f, 0.f);
+        B.wb = v3(0.f, 0.f, 0.f);
+        nstep = 0;
+    }
+    if (lead) {
+        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
+        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
+        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
+        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
+        P.st.nstep[env] = nstep;
+        if (rst) P.st.episode[env] += 1;
+    }
+    if (live && lead_leg) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = 3 * k + i;
+            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : J.q[i];
+            P.st.qvel[(6 + j) * n + env] = rst ? 0.f : J.qd[i];
+            P.st.act[j * n + env] = rst ? 0.f : J.act[i];
+            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? Tk.default_ctrl[j] : aclip[i];
+        }
+    }
     if (lead_env) {
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
@@ -476,7 +510,6 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         }
     }
     QG_MARK(3);                                      // obs tile written out
-    const bool lead = live && lead_env;
     if (lead && !P.packed) {
         if constexpr (!WALK) P.reward[env] = reward;
         P.done[env] = done ? 1 : 0;
@@ -493,20 +526,6 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         P.comps[(size_t)env * 3 + 0] = c_fwd;
         P.comps[(size_t)env * 3 + 1] = c_ctl;
         P.comps[(size_t)env * 3 + 2] = c_alive;
-    }
-    const bool rst = done && Tk.auto_reset;
-    if (rst) {
-        B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
-        B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
-        if (Tk.reset_flags & 1u) {
-            float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)P.st.episode[env]);
-            float sn, cs;
-            sincos_f(0.5f * a, sn, cs);
-            B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
-        }
-        B.vw = v3(0.f, 0.f, 0.f);
-        B.wb = v3(0.f, 0.f, 0.f);
-        nstep = 0;
     }
     QG_MARK(6);
     if constexpr (PO) {
@@ -534,23 +553,5 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
     }
     QG_MARK(8);
-    if (lead) {
-        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
-        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
-        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
-        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
-        P.st.nstep[env] = nstep;
-        if (rst) P.st.episode[env] += 1;
-    }
-    if (live && lead_leg) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = 3 * k + i;
-            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : J.q[i];
-            P.st.qvel[(6 + j) * n + env] = rst ? 0.f : J.qd[i];
-            P.st.act[j * n + env] = rst ? 0.f : J.act[i];
-            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? Tk.default_ctrl[j] : aclip[i];
-        }
-    }
     QG_MARK(9);                                      // every store issued
 }
