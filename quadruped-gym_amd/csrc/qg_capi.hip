@@ -636,7 +636,7 @@ extern "C" int qg_walk_destroy(qg_walk *w) {
         if (build_tables(&s->model, &s->task, &km, &kt) == QG_OK) (void)hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice);
     }
     void *ptrs[] = {w->st.vel, w->st.head, w->st.gvel, w->st.ideal, w->st.prev_ctrl, w->st.prev_ctrl_cost, w->st.has_ctrl_cost,
-                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.omax, w->st.omin, w->st.cross, w->st.count, w->st.prev, w->st.sign,
+                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.smax, w->st.smin, w->st.omax, w->st.omin, w->st.cross, w->st.count, w->st.prev, w->st.sign,
                     w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -696,6 +696,7 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
         const size_t nb = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK, Wp = nb * QG_WALK_BLOCK;
         WALLOC(w->st.sig, Wp * 12 * n * 4); WALLOC(w->st.cross, Wp * 12 * n);
         WALLOC(w->st.bmax, (size_t)QG_WALK_MAXBLOCKS * 12 * n * 4); WALLOC(w->st.bmin, (size_t)QG_WALK_MAXBLOCKS * 12 * n * 4);
+        WALLOC(w->st.smax, (size_t)QG_WALK_BLOCK * 12 * n * 4); WALLOC(w->st.smin, (size_t)QG_WALK_BLOCK * 12 * n * 4);
     }
     WALLOC(w->st.omax, 12 * n * 4); WALLOC(w->st.omin, 12 * n * 4); WALLOC(w->st.count, 12 * n * 4);
     WALLOC(w->st.prev, 12 * n * 4); WALLOC(w->st.sign, 12 * n * 4); WALLOC(w->st.f_est, 12 * n * 4); WALLOC(w->st.a_est, 12 * n * 4);

@@ -516,7 +516,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     }
     if constexpr (WALK) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
-        if (wch) walk_channel_terms(WK.S, env, jch, wtg, sel3(r, aclip[0], aclip[1], aclip[2]), wprev, wf[0], wa[0], sum);
+        if (wch) {
+            const float c_own = sel3(r, aclip[0], aclip[1], aclip[2]);
+            walk_channel_terms(WK.S, env, jch, wtg, c_own, wprev, wf[0], wa[0], sum);
+            WK.S.prev_ctrl[tt[0]] = c_own;
+        }
         sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
         QG_MARK(4);                                  // channel terms + sums
         if (lead) walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);

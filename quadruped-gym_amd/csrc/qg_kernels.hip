@@ -1148,10 +1148,8 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     WalkChanTargets wtg[3] = {};
     if constexpr (WALK) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            xx[i] = P.st.ctrl[(3 * k + i) * n + env]; // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
-            wprev[i] = WK.S.prev_ctrl[tt[i]];         // previous_ctrl of the control cost (:260-262)
-        }
+        for (int i = 0; i < 3; ++i) xx[i] = P.st.ctrl[(3 * k + i) * n + env];   // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+        walk_ldv<3>(WK.S.prev_ctrl + tt[0], wprev);   // previous_ctrl of the control cost (:260-262)
         walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
         if constexpr (WPE == 1) {
 #pragma unroll
@@ -1186,8 +1184,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
                      "v"(L.act[0]), "v"(L.act[1]), "v"(L.act[2]), "v"(L.u[0]), "v"(L.u[1]), "v"(L.u[2]) : "memory");
         if (live) {
             walk_estimator_finish_n<3>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
-#pragma unroll
-            for (int i = 0; i < 3; ++i) WK.S.eff_actions[(size_t)env * 12 + 3 * k + i] = a_eff[i];   // the action actually applied (the PO pack reads it)
+            walk_stv<3>(WK.S.eff_actions + (size_t)env * 12 + 3 * k, a_eff);                        // the action actually applied (the PO pack reads it)
         }
     }
 
@@ -1322,6 +1319,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         if (live) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) walk_channel_terms(WK.S, env_e, 3 * k_e + i, wtg[i], aclip[i], wprev[i], wf[i], wa[i], sum);
+            walk_stv<3>(WK.S.prev_ctrl + (size_t)env_e * 12 + 3 * k_e, aclip);                       // previous_ctrl moves on (:260-262)
         }
         sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
         if (lead) walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
@@ -1539,7 +1537,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         for (int c6 = 0; c6 < 6; ++c6) {
             tt[c6] = env * 12 + 6 * half + c6;
             xx[c6] = P.st.ctrl[(6 * half + c6) * n + env];           // data.ctrl of the PREVIOUS step (walking_quad.py:136)
-            wprev[c6] = WK.S.prev_ctrl[tt[c6]];                      // previous_ctrl of the control cost (:260-262)
+        }
+        {
+            float pc[6];
+            walk_ldv<6>(WK.S.prev_ctrl + env * 12 + 6 * half, pc);    // previous_ctrl of the control cost (:260-262)
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) wprev[c6] = pc[c6];
         }
         walk_estimator_load_n<6>(WK.P, WK.S, n, tt, calls, west);
 #pragma unroll
@@ -1578,8 +1581,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
                      "v"(L.act[0].x), "v"(L.act[1].x), "v"(L.act[2].x), "v"(L.act[0].y), "v"(L.act[1].y), "v"(L.act[2].y) : "memory");
         if (live) {
             walk_estimator_finish_n<6>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
-#pragma unroll
-            for (int c6 = 0; c6 < 6; ++c6) WK.S.eff_actions[(size_t)env * 12 + 6 * half + c6] = a_eff[c6];
+            walk_stv<6>(WK.S.eff_actions + (size_t)env * 12 + 6 * half, a_eff);
         }
     }
 
@@ -1641,6 +1643,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         if (live) {
 #pragma unroll
             for (int c6 = 0; c6 < 6; ++c6) walk_channel_terms(WK.S, env, 6 * half + c6, wtg[c6], aclip[c6], wprev[c6], wf[c6], wa[c6], sum);
+            walk_stv<6>(WK.S.prev_ctrl + (size_t)env * 12 + 6 * half, aclip);                          // previous_ctrl moves on (:260-262)
         }
         sum.cost = pair_sum(sum.cost); sum.posture = pair_sum(sum.posture); sum.amp = pair_sum(sum.amp); sum.frq = pair_sum(sum.frq);
         QG_MARK(4);                                  // channel terms + sums

@@ -58,6 +58,7 @@ __global__ void qg_walk_post_kernel(KWalkParams P, KWalkState S, int n, const fl
         float c = S.eff_actions[(size_t)env * 12 + j];               // data.ctrl after the step
         c = fminf(fmaxf(c, -1.f), 1.f);                              // quadruped.py:160
         walk_channel_terms(S, env, j, walk_channel_targets(P, j), c, S.prev_ctrl[env * 12 + j], S.f_est[env * 12 + j], S.a_est[env * 12 + j], sum);
+        S.prev_ctrl[env * 12 + j] = c;
     }
     // the physics reset has already advanced the env's episode counter: the key of the episode that begins is episode - 1
     WalkEnvIn in = walk_env_load(S, n, env);

@@ -47,8 +47,9 @@ struct KWalkState {
     // estimator (math_utils.py): never reset between episodes (walking_quad.py:115)
     int32_t *calls;          // [n]      update() calls so far: buffer index = calls % window, samples = min(calls, window)
     float *sig;              // [window][n][12]
-    float *bmax, *bmin;      // [blocks][n][12]  max / min of each 16-sample block of the ring buffer
+    float *bmax, *bmin;      // [blocks][n][12]  max / min of the samples written into each 16-sample block during its latest pass
     float *omax, *omin;      // [n][12]  max / min over the filled blocks other than the one being written (cache, see walk_estimator_load_n)
+    float *smax, *smin;      // [16][n][12]  suffix max / min of the OLD samples of the block being written: [j] covers old[j .. 15]
     uint8_t *cross;          // [window][n][12]
     int32_t *count;          // [n][12]  running number of derivative sign changes inside the window
     float *prev;             // [n][12]
@@ -75,21 +76,73 @@ template <> struct WalkArgT<true> { typedef KWalkLaunch type; };
 // Per-channel task state is laid out ENV-MAJOR, channel-minor ([n][12]; ring buffers [slot][n][12]): the 12 channels of an env --
 // and the 48 of the four envs a wave of the one-link-per-lane kernel carries -- are contiguous.  Channel-major ([12][n], round 1)
 // made that kernel touch 12 separate 64-byte lines per load, 16 bytes of each: 7.4 us of task layer per walking step.
-// The amplitude is max - min over a sliding window of W samples.  The ring buffer carries per-block (16 samples) max / min
-// summaries, and -- new in round 2 -- the max / min over all OTHER filled blocks is cached while the write index stays inside one
-// block (it only changes when the index enters a new block, every 16th call), so a call touches the 16 samples of the current
-// block and eight scalars instead of 16 + 2 * 15 values behind a serial loop.  Written in three phases -- every load, then the
-// arithmetic, then every store -- so that the loads of all channels are in flight together: inside the fused step kernel a wave is
-// alone on its SIMD and a chain of dependent loads costs its full latency each time (measured: the loop form made the fused
-// walking step 42 us, slower than three launches).  max / min are exact, so the results are bit-identical to a full scan.
+// The amplitude is max - min over a sliding window of W samples.  max / min are exact, so however they are regrouped the result is
+// bit-identical to a full scan of the ring (the oracle pinned to the reference's math_utils.py checks it over window wraps).  Three
+// levels keep a call's traffic at twelve values per channel:
+//   * the ring is cut into blocks of 16 samples; bmax / bmin[b] hold the extrema of the samples written into block b during its
+//     latest pass (a running value while the write index is inside b, the block's summary once it has moved on);
+//   * omax / omin cache the extrema over all OTHER filled blocks: they only change when the write index enters a new block (every
+//     16th call), where they are rebuilt from the summaries;
+//   * what is left of the block being overwritten -- the OLD samples behind the write index, the oldest of the window -- enters
+//     through suffix extrema smax / smin[j] = extrema of old[j .. 15], computed once, when the index enters the block (third pass of
+//     round 2; before, every call re-read the block's 16 samples: 24 values per channel and call, ~1.7 KB of task state traffic per
+//     env-step, which is what bounds the walking step at large batches -- 13 us of HBM-bound prologue at 32 768 envs).
+// Written in three phases -- every load, then the arithmetic, then every store -- so that the loads of all channels are in flight
+// together: inside the fused step kernel a wave is alone on its SIMD and a chain of dependent loads costs its full latency each time
+// (measured: the loop form made the fused walking step 42 us, slower than three launches).
+// The NCH channels a lane owns are CONSECUTIVE (t[c] = t[0] + c: one, three or six of an env's twelve), i.e. contiguous in every
+// [..][n][12] array: they move as ONE 12-byte access per three channels (global_load / store_dwordx3 needs dword alignment only)
+// instead of three 4-byte ones that each use a third of every cache line they touch -- at 32 768 envs the six-channel update of the
+// two-legs-per-lane kernel spent 7.1 us in its 54 scalar stores per lane and 3.4 us in its loads (tools/phase_times.py).
+struct WalkF3 { float a, b, c; };
+struct WalkI3 { int a, b, c; };
+template <int NCH> __device__ __forceinline__ void walk_ldv(const float *p, float (&o)[NCH]) {
+    if constexpr (NCH % 3 == 0) {
+#pragma unroll
+        for (int g = 0; g < NCH / 3; ++g) { const WalkF3 v = *reinterpret_cast<const WalkF3 *>(p + 3 * g); o[3 * g] = v.a; o[3 * g + 1] = v.b; o[3 * g + 2] = v.c; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) o[c] = p[c];
+    }
+}
+template <int NCH> __device__ __forceinline__ void walk_ldv(const int *p, int (&o)[NCH]) {
+    if constexpr (NCH % 3 == 0) {
+#pragma unroll
+        for (int g = 0; g < NCH / 3; ++g) { const WalkI3 v = *reinterpret_cast<const WalkI3 *>(p + 3 * g); o[3 * g] = v.a; o[3 * g + 1] = v.b; o[3 * g + 2] = v.c; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) o[c] = p[c];
+    }
+}
+template <int NCH> __device__ __forceinline__ void walk_stv(float *p, const float (&v)[NCH]) {
+    if constexpr (NCH % 3 == 0) {
+#pragma unroll
+        for (int g = 0; g < NCH / 3; ++g) { const WalkF3 w = {v[3 * g], v[3 * g + 1], v[3 * g + 2]}; *reinterpret_cast<WalkF3 *>(p + 3 * g) = w; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) p[c] = v[c];
+    }
+}
+template <int NCH> __device__ __forceinline__ void walk_stv(int *p, const int (&v)[NCH]) {
+    if constexpr (NCH % 3 == 0) {
+#pragma unroll
+        for (int g = 0; g < NCH / 3; ++g) { const WalkI3 w = {v[3 * g], v[3 * g + 1], v[3 * g + 2]}; *reinterpret_cast<WalkI3 *>(p + 3 * g) = w; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) p[c] = v[c];
+    }
+}
 #define QG_WALK_MAXBLOCKS 16              // the ring buffer and its summaries are allocated for 16 blocks (window <= 256 samples)
-#define QG_WALK_EMPTY_MAX (-3.0e38f)      // "no other block yet" (finite: the device pass is compiled with -ffinite-math-only)
+#define QG_WALK_EMPTY_MAX (-3.0e38f)      // "nothing there" (finite: the device pass is compiled with -ffinite-math-only)
 #define QG_WALK_EMPTY_MIN (3.0e38f)
 template <int NCH> struct WalkEstIn {
-    float prev[NCH], psign[NCH], fe[NCH], ae[NCH], om[NCH], on[NCH], blk[NCH][QG_WALK_BLOCK];
+    float prev[NCH], psign[NCH], fe[NCH], ae[NCH], om[NCH], on[NCH];
+    float bm[NCH], bn[NCH];               // extrema of the samples written into the current block so far (valid when j0 > 0)
+    float sh[NCH], sl[NCH];               // extrema of the old samples still standing behind the write index (EMPTY if none)
     int cnt[NCH], cr[NCH];
 };
-// phase 1: every load of the update (nothing is stored): call it among the caller's other loads
+// phase 1: every load of the update: call it among the caller's other loads.  (On the call that enters a new block -- every 16th --
+// it also reads the block's 16 old samples and the 2 x 16 summaries and STORES the suffix extrema: a rare, slower path.)
 template <int NCH>
 __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], int calls, WalkEstIn<NCH> &in) {
     const int W = P.window;
@@ -98,27 +151,45 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
     const int samples = min(calls + 1, W);              // :89-90
     const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK, base = bidx * QG_WALK_BLOCK;
     const int nblocks = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
+    const int jn = min(j0 + 1, QG_WALK_BLOCK - 1);      // suffix slot behind the write index (clamped: slot 16 does not exist)
+    const bool has_old = j0 + 1 < QG_WALK_BLOCK;
+    const int t0 = t[0];                                // t[c] = t0 + c
+    walk_ldv<NCH>(S.prev + t0, in.prev);
+    walk_ldv<NCH>(S.sign + t0, in.psign);
+    walk_ldv<NCH>(S.count + t0, in.cnt);
+    walk_ldv<NCH>(S.f_est + t0, in.fe);
+    walk_ldv<NCH>(S.a_est + t0, in.ae);
+    walk_ldv<NCH>(S.omax + t0, in.om);
+    walk_ldv<NCH>(S.omin + t0, in.on);
+    walk_ldv<NCH>(S.bmax + (size_t)bidx * stride + t0, in.bm);
+    walk_ldv<NCH>(S.bmin + (size_t)bidx * stride + t0, in.bn);
+    walk_ldv<NCH>(S.smax + (size_t)jn * stride + t0, in.sh);
+    walk_ldv<NCH>(S.smin + (size_t)jn * stride + t0, in.sl);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const size_t slot = (size_t)idx * stride + t[c];
-        in.prev[c] = S.prev[t[c]];
-        in.psign[c] = S.sign[t[c]];
-        in.cnt[c] = S.count[t[c]];
-        in.cr[c] = (int)S.cross[slot];                  // the slot holds 0 until the buffer wraps
-        in.fe[c] = S.f_est[t[c]];
-        in.ae[c] = S.a_est[t[c]];
-        in.om[c] = S.omax[t[c]];
-        in.on[c] = S.omin[t[c]];
-        const float *col = S.sig + t[c] + (size_t)base * stride;
-#pragma unroll
-        for (int j = 0; j < QG_WALK_BLOCK; ++j) in.blk[c][j] = col[(size_t)j * stride];   // unconditional: the ring is allocated in whole blocks
+        in.cr[c] = (int)S.cross[(size_t)idx * stride + t0 + c];     // the slot holds 0 until the buffer wraps
+        in.sh[c] = has_old ? in.sh[c] : QG_WALK_EMPTY_MAX;
+        in.sl[c] = has_old ? in.sl[c] : QG_WALK_EMPTY_MIN;
     }
-    if (calls > 0 && j0 == 0) {                         // the write index enters block bidx: the cache of the other blocks is rebuilt
+    if (calls > 0 && j0 == 0) {                         // the write index enters block bidx
+        // (a) the cache of the other blocks is rebuilt from the summaries
         float hi[NCH][QG_WALK_MAXBLOCKS], lo[NCH][QG_WALK_MAXBLOCKS];
 #pragma unroll
         for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // every summary slot exists (16 blocks are allocated whatever the window): plain loads ...
+            float h[NCH], l[NCH];
+            walk_ldv<NCH>(S.bmax + (size_t)b * stride + t0, h);
+            walk_ldv<NCH>(S.bmin + (size_t)b * stride + t0, l);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { hi[c][b] = S.bmax[(size_t)b * stride + t[c]]; lo[c][b] = S.bmin[(size_t)b * stride + t[c]]; }
+            for (int c = 0; c < NCH; ++c) { hi[c][b] = h[c]; lo[c][b] = l[c]; }
+        }
+        // (b) the block's old samples: the ring is allocated in whole blocks, so the 16 loads are unconditional
+        float old[NCH][QG_WALK_BLOCK];
+#pragma unroll
+        for (int j = 0; j < QG_WALK_BLOCK; ++j) {
+            float o[NCH];
+            walk_ldv<NCH>(S.sig + (size_t)(base + j) * stride + t0, o);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) old[c][j] = o[c];
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { in.om[c] = QG_WALK_EMPTY_MAX; in.on[c] = QG_WALK_EMPTY_MIN; }
@@ -131,6 +202,26 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
                 in.on[c] = fminf(in.on[c], use ? lo[c][b] : QG_WALK_EMPTY_MIN);
             }
         }
+        // suffix extrema of the old samples, filled slots only (slot < samples: none before the buffer has wrapped, and the last
+        // block of a window that is not a multiple of 16 ends early); slot j is stored for the call that writes sample j - 1
+        {
+            float sh[NCH], sl[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { sh[c] = QG_WALK_EMPTY_MAX; sl[c] = QG_WALK_EMPTY_MIN; }
+#pragma unroll
+            for (int j = QG_WALK_BLOCK - 1; j >= 1; --j) {
+                const bool valid = base + j < samples;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    sh[c] = fmaxf(sh[c], valid ? old[c][j] : QG_WALK_EMPTY_MAX);
+                    sl[c] = fminf(sl[c], valid ? old[c][j] : QG_WALK_EMPTY_MIN);
+                }
+                walk_stv<NCH>(S.smax + (size_t)j * stride + t0, sh);
+                walk_stv<NCH>(S.smin + (size_t)j * stride + t0, sl);
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { in.sh[c] = sh[c]; in.sl[c] = sl[c]; }     // j = 1: what stands behind the sample this call writes
+        }
     }
 }
 // phases 2 and 3: the arithmetic and every store; returns the new estimates (what the reward of this step reads)
@@ -141,6 +232,11 @@ __device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, co
     const int idx = calls % W;
     const size_t stride = (size_t)12 * n;
     if (calls == 0) {                                   // first call: remember the sample, estimates stay 0 (:66-72)
+        // (the estimates are handed back BEFORE the stores below: with an assignment to the caller's arrays as the last statement of
+        // this branch and a global store as the last one of the other, the optimiser sinks both into one store through a pointer phi
+        // and the caller's array ends up in scratch memory)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { f_new[c] = in.fe[c]; a_new[c] = in.ae[c]; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             S.prev[t[c]] = x[c];
@@ -149,47 +245,49 @@ __device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, co
             S.bmin[t[c]] = x[c];
             S.omax[t[c]] = QG_WALK_EMPTY_MAX;
             S.omin[t[c]] = QG_WALK_EMPTY_MIN;
-            f_new[c] = in.fe[c];
-            a_new[c] = in.ae[c];
+#pragma unroll
+            for (int j = 1; j < QG_WALK_BLOCK; ++j) {   // nothing stands behind the write index of block 0 yet
+                S.smax[(size_t)j * stride + t[c]] = QG_WALK_EMPTY_MAX;
+                S.smin[(size_t)j * stride + t[c]] = QG_WALK_EMPTY_MIN;
+            }
         }
         return;
     }
     const int samples = min(calls + 1, W);              // :89-90
-    const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK, base = bidx * QG_WALK_BLOCK;
+    const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK;
     const bool enter = j0 == 0;
+    const float rdur = walk_rcp((float)samples * P.dt); // :109
+    const int t0 = t[0];                                // t[c] = t0 + c
+    float mxs[NCH], mns[NCH], curs[NCH], xs[NCH];
+    int counts[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const size_t slot = (size_t)idx * stride + t[c];
         float d = x[c] - in.prev[c];
         float cur = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
         const bool have_sign = calls >= 2;              // a previous derivative sign exists (:78-86)
         cur = (have_sign && cur == 0.f) ? in.psign[c] : cur;
         const int crossing = (have_sign && cur != in.psign[c]) ? 1 : 0;
         const int count = in.cnt[c] - in.cr[c] + crossing;                      // :94-96
-        const float dur = (float)samples * P.dt;        // :109
-        const float f_cur = (0.5f * (float)count) * walk_rcp(dur);              // :113-114
-        float mx = x[c], mn = x[c];
-#pragma unroll
-        for (int j = 0; j < QG_WALK_BLOCK; ++j) {
-            const int slot_j = base + j;                // filled slots only (samples == W once the buffer has wrapped), not the one being written
-            const float v = (slot_j < samples && slot_j != idx) ? in.blk[c][j] : x[c];
-            mx = fmaxf(mx, v);
-            mn = fminf(mn, v);
-        }
-        const float amp = fmaxf(mx, in.om[c]) - fminf(mn, in.on[c]);            // :121-126
+        const float f_cur = (0.5f * (float)count) * rdur;                       // :113-114
+        // the samples written into this block so far, the new one included ...
+        const float mx = enter ? x[c] : fmaxf(in.bm[c], x[c]);
+        const float mn = enter ? x[c] : fminf(in.bn[c], x[c]);
+        // ... the old ones still standing behind it, and every other block
+        const float amp = fmaxf(fmaxf(mx, in.sh[c]), in.om[c]) - fminf(fminf(mn, in.sl[c]), in.on[c]);   // :121-126
         f_new[c] = P.ema_alpha * in.fe[c] + (1.f - P.ema_alpha) * f_cur;        // :117
         a_new[c] = P.ema_alpha * in.ae[c] + (1.f - P.ema_alpha) * amp;          // :129
-        S.cross[slot] = (uint8_t)crossing;
-        S.count[t[c]] = count;
-        S.sig[slot] = x[c];                             // :99
-        S.prev[t[c]] = x[c];                            // :105-106
-        S.sign[t[c]] = cur;
-        S.f_est[t[c]] = f_new[c];
-        S.bmax[(size_t)bidx * stride + t[c]] = mx;      // summary of the current block, the new sample included
-        S.bmin[(size_t)bidx * stride + t[c]] = mn;
-        if (enter) { S.omax[t[c]] = in.om[c]; S.omin[t[c]] = in.on[c]; }
-        S.a_est[t[c]] = a_new[c];
+        S.cross[(size_t)idx * stride + t0 + c] = (uint8_t)crossing;
+        counts[c] = count; mxs[c] = mx; mns[c] = mn; curs[c] = cur; xs[c] = x[c];
     }
+    walk_stv<NCH>(S.count + t0, counts);
+    walk_stv<NCH>(S.sig + (size_t)idx * stride + t0, xs);                       // :99
+    walk_stv<NCH>(S.prev + t0, xs);                                             // :105-106
+    walk_stv<NCH>(S.sign + t0, curs);
+    walk_stv<NCH>(S.f_est + t0, f_new);
+    walk_stv<NCH>(S.bmax + (size_t)bidx * stride + t0, mxs);                    // the block's summary once the write index has moved on
+    walk_stv<NCH>(S.bmin + (size_t)bidx * stride + t0, mns);
+    if (enter) { walk_stv<NCH>(S.omax + t0, in.om); walk_stv<NCH>(S.omin + t0, in.on); }
+    walk_stv<NCH>(S.a_est + t0, a_new);
 }
 
 // ---- per-channel contributions to the reward sums; also moves previous_ctrl on (walking_quad.py:249-285) ------------------
@@ -205,8 +303,7 @@ __device__ __forceinline__ WalkChanTargets walk_channel_targets(const KWalkParam
 __device__ __forceinline__ void walk_channel_terms(const KWalkState &S, int env, int j, const WalkChanTargets &T, float c /* data.ctrl, clipped */,
                                                    float prev_ctrl, float f_est, float a_est, WalkSums &a) {
     const float inv_nu = 1.f / 12.f;
-    float dc = c - prev_ctrl;                                        // control_cost (:254-270)
-    S.prev_ctrl[env * 12 + j] = c;
+    float dc = c - prev_ctrl;                                        // control_cost (:254-270); the CALLER moves previous_ctrl on (walk_stv)
     a.cost = fmaf(dc, dc, a.cost);
     float pj = (c - T.center) * inv_nu;                              // :249-253
     a.posture = fmaf(pj, pj, a.posture);
