@@ -448,7 +448,7 @@ def main():
                                    + (", random yaw at reset" if args.random_yaw else "")
                                    + (f", hinge jitter {args.joint_jitter} rad at reset" if args.joint_jitter > 0 else "")
                                    + (f", hipGraph of {args.graph} env-steps per replay" if args.graph > 0 else "")
-                                   + (", WALKING task layer (estimator + 11-term reward + flip termination; 3 kernels per env-step)" if args.walking else "")
+                                   + (", WALKING task layer (estimator + 11-term reward + flip termination), one launch per env-step" if args.walking else "")
                                    + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 from the library's C loop (qg_comm_rollout, overlapped)" if native is not None else
                                       (f", per-step RCCL {args.gather_op} of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if use_dist else "")),
                        "envs_per_gpu": n, "frame_skip": args.frame_skip, "obs_dim": od, "mapping": mapping_name,

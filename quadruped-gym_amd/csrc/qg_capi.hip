@@ -597,10 +597,9 @@ struct qg_walk {
     uint8_t *d_done;
 };
 
-// The walking env-step is ONE launch wherever the one-leg-per-lane kernel is what runs (AUTO: up to 16 384 envs and between 32 769
-// and 57 343; an explicit QUAD: always): 23.3 us against 33.0 us for estimator -> physics -> reward at 4096 envs.  Where AUTO takes
-// the two-legs-per-lane kernel (16 385 .. 32 768 envs, >= 57 344) the three launches around it stay ahead (46.6 us against 52.5 us
-// fused at 32 768 envs); LANE / PAIR requests keep the three launches too.
+// The walking env-step is ONE launch with every mapping AUTO can pick -- the task layer is fused into the one-link-per-lane, the
+// one-leg-per-lane and the two-legs-per-lane kernels (16.9 us at 4096 envs, 33.9 us at 32 768; estimator -> physics -> reward as
+// three launches measured 33.0 and 46.7 us).  Only an explicit LANE request keeps the three launches.
 static bool walk_fused(const qg_sim *s) { const int m = effective_mapping(s); return m == QG_MAP_QUAD || m == QG_MAP_LINK || m == QG_MAP_PAIR; }
 
 extern "C" int qg_walk_default_params(qg_walk_params *p) {
