@@ -13,7 +13,7 @@ N > 1: one process per GPU, env batches sharded (4096 per GPU, weak scaling), no
 physics; per env-step ONE RCCL gather of the packed [envs, obs+2] f32 buffer (obs, reward, done) to
 rank 0 over xGMI, issued on a communication stream and overlapped with the next env-step.  The K timed
 steps are measured with the host issuing kernel + collective per step (eager); then, unless --exchange eager,
-the same K steps are measured again as replays of a hipGraph of 8 env-steps under a watchdog, and the faster
+the same K steps are measured again as replays of a hipGraph of up to 16 env-steps under a watchdog, and the faster
 of the two is reported (`config.exchange` says which; a failed or stalled attempt leaves the eager result).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the step kernel against HBM (algorithmic bytes per
@@ -32,6 +32,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on this stack needs dmabuf IPC (the host driver has no legacy IPC): RCCL / tensor sharing across ranks fail
+# with hipIpcGetMemHandle "invalid argument" otherwise.  Already exported on the boxes; set here too so a bare launcher inherits it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 STALL_EXIT = 3                 # exit status when the hipGraph attempt of --exchange auto hangs the GPU (the eager line is still printed)
