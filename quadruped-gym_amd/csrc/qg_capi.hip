@@ -1024,7 +1024,13 @@ extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *rew
     HIP_TRY(hipMemcpyAsync(reward, w->d_reward, n * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
     HIP_TRY(hipMemcpyAsync(done, w->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
     if (components) HIP_TRY(hipMemcpyAsync(components, w->d_comps, n * QG_NWALKREWARD * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, p->d_term, n * width * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
     HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    if (terminal_obs) {
+        // the terminal stacks only exist for envs that finished: the [n][obs_dim] transfer (4.3 MB at 4096 envs and window 10 -- as much
+        // as the observation itself) is skipped on the steps where none did
+        bool any = false;
+        for (size_t i = 0; i < n && !any; i++) any = done[i] != 0;
+        if (any) HIP_TRY(hipMemcpy(terminal_obs, p->d_term, n * width * 4, hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    }
     return QG_OK;
 }

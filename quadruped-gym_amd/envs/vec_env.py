@@ -34,6 +34,7 @@ import numpy as np
 from .. import _abi
 from ..model.loader import load_model
 from ..sim import BatchedSim
+from .infos import LazyInfos
 from .quadruped import ModelView
 from .spaces import Box
 
@@ -287,24 +288,27 @@ class QuadrupedVecEnv(_VecEnvBase):
                 rew = rew + v
             rew = rew.astype(np.float32)
             done = done | host_done
-        infos = []
         active = [k for k in names if k in self.reward_fns and not callable(self.reward_fns[k])]
         cols = [names.index(k) for k in active]
-        rows = comps[:, cols].tolist() if cols else [[] for _ in range(self.num_envs)]   # one C-level conversion
         defaults = [k for k, v in self.reward_fns.items() if callable(v) and v == self._default_reward]
-        for i, row in enumerate(rows):
-            rc = dict(zip(active, row))
+        finished = np.nonzero(done)[0]
+        # the reference reports the time limit as `terminated`
+        extra = {int(i): {"terminal_observation": obs[i].copy(), "TimeLimit.truncated": False} for i in finished}
+        picked = comps[:, cols] if cols else None
+
+        def make(i):                                        # infos[i], built the first time it is touched (envs/infos.py)
+            rc = dict(zip(active, picked[i].tolist())) if cols else {}
             for name in defaults:
                 rc[name] = 0.0                              # quadruped.py:145-147
             for name, v in host_comps.items():
                 rc[name] = float(v[i])
             info = dict(rc)
             info["reward_components"] = rc
-            infos.append(info)
-        finished = np.nonzero(done)[0]
-        for i in finished:
-            infos[i]["terminal_observation"] = obs[i].copy()
-            infos[i]["TimeLimit.truncated"] = False         # the reference reports the time limit as `terminated`
+            e = extra.get(i)
+            if e:
+                info.update(e)
+            return info
+        infos = LazyInfos(self.num_envs, make)
         if host and finished.size:
             self._sim.reset(mask=done.astype(np.uint8), flags=self._reset_flags)    # draws from the batch's own streams
         if finished.size:

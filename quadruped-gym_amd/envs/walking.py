@@ -14,6 +14,7 @@ from .._abi import NWALKREWARD, QgWalkParams, check
 from ..model.loader import load_model
 from ..sim import BatchedSim
 from .quadruped import ModelView
+from .infos import LazyInfos
 from .spaces import Box
 
 REWARD_KEYS = ["alive_bonus", "control_cost", "progress_direction_reward_local", "progress_speed_cost_local",
@@ -132,16 +133,16 @@ class WalkingQuadrupedVecEnv:
         check(self._lib.qg_walk_step(self._w, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, comps.ctypes.data),
               "qg_walk_step")
         dones = done.astype(bool)
-        infos = [dict(zip(REWARD_KEYS, row)) for row in comps.tolist()]
+        extra = {}
         if self.auto_reset:
             for i in np.nonzero(dones)[0]:
-                infos[i]["terminal_observation"] = obs[i].copy()
-                infos[i]["TimeLimit.truncated"] = False
-            if dones.any():
-                obs = obs.copy()
-                obs[dones] = 0.0
-                if self.random_controls:
-                    self._resample(np.nonzero(dones)[0])
+                extra[int(i)] = {"terminal_observation": obs[i].copy(), "TimeLimit.truncated": False}
+        infos = _component_infos(n, comps, extra)
+        if self.auto_reset and dones.any():
+            obs = obs.copy()
+            obs[dones] = 0.0
+            if self.random_controls:
+                self._resample(np.nonzero(dones)[0])
         self.last_components = comps
         return obs, rew, dones, infos
 
@@ -173,6 +174,18 @@ class WalkingQuadrupedVecEnv:
     def seed(self, seed=None):
         self._seed = 0 if seed is None else int(seed)
         return [self._seed + i for i in range(self.num_envs)]
+
+
+def _component_infos(n, comps, extra):
+    """``infos`` of a walking step: per env the reward-component dict the reference returns as ``info`` (walking_quad.py:419), plus
+    the SB3 entries of the envs in ``extra``; built on first access (see envs/infos.py)."""
+    def make(i):
+        d = dict(zip(REWARD_KEYS, comps[i].tolist()))
+        e = extra.get(i)
+        if e:
+            d.update(e)
+        return d
+    return LazyInfos(n, make)
 
     def get_attr(self, attr_name, indices=None):
         idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
@@ -273,20 +286,22 @@ class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
         if a.shape != (n, 12):
             raise ValueError(f"actions must have shape ({n}, 12)")
         obs = np.empty((n, self.obs_dim), np.float32)
-        term = np.empty((n, self.obs_dim), np.float32)
+        if getattr(self, "_term_buf", None) is None:       # scratch for the library's terminal stacks (rows are copied out below)
+            self._term_buf = np.empty((n, self.obs_dim), np.float32)
+        term = self._term_buf
         rew = np.empty(n, np.float32)
         done = np.empty(n, np.uint8)
         comps = np.empty((n, NWALKREWARD), np.float32)
         check(self._lib.qg_po_step(self._po, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data, comps.ctypes.data,
                                    term.ctypes.data), "qg_po_step")
         dones = done.astype(bool)
-        infos = [dict(zip(REWARD_KEYS, row)) for row in comps.tolist()]
+        extra = {}
         if self.auto_reset:
             for i in np.nonzero(dones)[0]:
-                infos[i]["terminal_observation"] = term[i].copy()
-                infos[i]["TimeLimit.truncated"] = False
-            if dones.any() and self.random_controls:
-                self._resample(np.nonzero(dones)[0])
+                extra[int(i)] = {"terminal_observation": term[i].copy(), "TimeLimit.truncated": False}
+        infos = _component_infos(n, comps, extra)
+        if self.auto_reset and dones.any() and self.random_controls:
+            self._resample(np.nonzero(dones)[0])
         self.last_components = comps
         return obs, rew, dones, infos
 

@@ -292,3 +292,28 @@ def test_handles_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (1 << 20), f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned after 30 cycles"
+
+
+def test_lazy_infos_is_a_list_of_dicts_built_on_demand():
+    """envs/infos.py: what step() returns as `infos` behaves like the plain list of dicts it replaces -- indexing (negative too),
+    slicing, iteration, len, in-place edits, equality, pickling -- while building each dict at most once and only when touched."""
+    import copy
+    import pickle
+    from quadruped_gym_amd.envs.infos import LazyInfos
+    built = []
+
+    def make(i):
+        built.append(i)
+        return {"i": i, "sq": i * i}
+    infos = LazyInfos(6, make)
+    assert isinstance(infos, list) and len(infos) == 6 and built == []
+    assert infos[2] == {"i": 2, "sq": 4} and infos[-1]["i"] == 5 and built == [2, 5]
+    infos[2]["episode"] = {"r": 1.0}                       # what VecMonitor does
+    assert infos[2]["episode"] == {"r": 1.0} and built == [2, 5]          # cached: not rebuilt
+    assert [d["i"] for d in infos[1:4]] == [1, 2, 3] and isinstance(infos[:], list) and not isinstance(infos[:], LazyInfos)
+    assert [d["i"] for d in infos] == list(range(6)) and sorted(built) == list(range(6)) and len(built) == 6
+    plain = [{"i": i, "sq": i * i} for i in range(6)]
+    plain[2]["episode"] = {"r": 1.0}
+    assert infos == plain and not (infos != plain) and list(reversed(infos))[0]["i"] == 5
+    assert pickle.loads(pickle.dumps(infos)) == plain and copy.deepcopy(infos) == plain and type(copy.deepcopy(infos)) is list
+    assert repr(infos) == repr(plain) and infos.copy() == plain and plain[3] in infos
