@@ -34,6 +34,8 @@ struct qg_sim {
     KState st;
     // staging for the host-pointer entry points
     float *d_actions, *d_obs, *d_reward, *d_comps, *d_stage;
+    uint8_t *h_pin;           // page-locked staging of the host-pointer entry points (see pin_reserve)
+    size_t h_pin_cap;
     uint8_t *d_done, *d_mask;
     hipStream_t stream;       // the library's own stream (host-pointer calls, timing)
     hipEvent_t ev0, ev1;
@@ -104,6 +106,7 @@ extern "C" int qg_destroy(qg_sim *s) {
                     s->d_obs,   s->d_reward, s->d_comps, s->d_stage, s->d_done, s->d_mask};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -353,19 +356,62 @@ extern "C" int qg_step_device_packed(qg_sim *s, const float *actions, float *pac
     return launch_step(s, actions, nullptr, nullptr, nullptr, nullptr, packed, (hipStream_t)stream);
 }
 
+// ---- page-locked staging of the host-pointer entry points --------------------------------------------------------------------------
+// The caller's buffers are ordinary (pageable) memory: a hipMemcpyAsync from / to them is a synchronous, staged copy with ~10-15 us of
+// fixed cost each -- five of them made a ONE-env qg_step 70 us for a 10 us kernel.  The entry points therefore copy through one
+// page-locked arena per handle: host memcpy in, truly asynchronous transfers enqueued around the launch, one stream synchronisation,
+// host memcpy out (tools/host_step_rate.py).
+struct PinOut { void *user; size_t off, bytes; };
+static int pin_reserve(qg_sim *s, size_t bytes) {
+    if (bytes <= s->h_pin_cap) return QG_OK;
+    if (s->h_pin) { (void)hipHostFree(s->h_pin); s->h_pin = nullptr; s->h_pin_cap = 0; }
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIP_TRY(hipHostMalloc((void **)&s->h_pin, cap, hipHostMallocDefault), QG_ERR_ALLOC);
+    s->h_pin_cap = cap;
+    return QG_OK;
+}
+static size_t pin_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// actions (host) -> device through the arena's first bytes, asynchronously on the library's stream
+static int pin_actions_in(qg_sim *s, const float *actions, float *d_actions) {
+    const size_t bytes = (size_t)s->n * QG_NU * sizeof(float);
+    memcpy(s->h_pin, actions, bytes);
+    HIP_TRY(hipMemcpyAsync(d_actions, s->h_pin, bytes, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
+    return QG_OK;
+}
+// Above ~1 MB the detour loses: the extra host copy into the caller's (often freshly allocated, not yet touched) array costs more than
+// the staged transfer's fixed overhead -- the 4.3 MB observation stack of 4096 partially observable envs went from 213 to 369 us per step
+// through the arena -- so large outputs go straight to the caller's memory.
+#define QG_PIN_MAX_BYTES ((size_t)1 << 20)
+static int pin_out_enqueue(qg_sim *s, const PinOut &o, const void *d_src) {
+    if (!o.user) return QG_OK;
+    void *dst = o.bytes > QG_PIN_MAX_BYTES ? o.user : (void *)(s->h_pin + o.off);
+    HIP_TRY(hipMemcpyAsync(dst, d_src, o.bytes, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
+    return QG_OK;
+}
+static void pin_out_finish(qg_sim *s, const PinOut &o) {
+    if (o.user && o.bytes <= QG_PIN_MAX_BYTES) memcpy(o.user, s->h_pin + o.off, o.bytes);
+}
+
 extern "C" int qg_step(qg_sim *s, const float *actions, float *obs, float *reward, uint8_t *done, float *comps) {
     if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step: null argument");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     size_t n = (size_t)s->n;
-    HIP_TRY(hipMemcpyAsync(s->d_actions, actions, n * QG_NU * sizeof(float), hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
-    int rc = launch_step(s, s->d_actions, s->d_obs, s->d_reward, s->d_done, comps ? s->d_comps : nullptr, nullptr, s->stream);
+    size_t off = pin_align(n * QG_NU * sizeof(float));
+    PinOut o_obs = {obs, off, n * s->obs_dim * sizeof(float)};       off += pin_align(o_obs.bytes);
+    PinOut o_rew = {reward, off, n * sizeof(float)};                   off += pin_align(o_rew.bytes);
+    PinOut o_done = {done, off, n};                                    off += pin_align(o_done.bytes);
+    PinOut o_comp = {comps, off, n * QG_NREWARD * sizeof(float)};      off += pin_align(o_comp.bytes);
+    int rc = pin_reserve(s, off);
+    if (rc == QG_OK) rc = pin_actions_in(s, actions, s->d_actions);
+    if (rc == QG_OK) rc = launch_step(s, s->d_actions, s->d_obs, s->d_reward, s->d_done, comps ? s->d_comps : nullptr, nullptr, s->stream);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_obs, s->d_obs);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_rew, s->d_reward);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_done, s->d_done);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_comp, s->d_comps);
     if (rc != QG_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(obs, s->d_obs, n * s->obs_dim * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipMemcpyAsync(reward, s->d_reward, n * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipMemcpyAsync(done, s->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    if (comps) HIP_TRY(hipMemcpyAsync(comps, s->d_comps, n * QG_NREWARD * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
     HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    pin_out_finish(s, o_obs); pin_out_finish(s, o_rew); pin_out_finish(s, o_done); pin_out_finish(s, o_comp);
     return QG_OK;
 }
 
@@ -857,14 +903,21 @@ extern "C" int qg_walk_step(qg_walk *w, const float *actions, float *obs, float 
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     size_t n = (size_t)s->n;
-    HIP_TRY(hipMemcpyAsync(w->d_actions, actions, n * 12 * 4, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
-    int rc = qg_walk_step_device(w, w->d_actions, w->d_obs, w->d_reward, w->d_done, components ? w->d_comps : nullptr, s->stream);
+    size_t off = pin_align(n * QG_NU * sizeof(float));
+    PinOut o_obs = {obs, off, n * QG_NSENSOR * 4};                     off += pin_align(o_obs.bytes);
+    PinOut o_rew = {reward, off, n * 4};                               off += pin_align(o_rew.bytes);
+    PinOut o_done = {done, off, n};                                    off += pin_align(o_done.bytes);
+    PinOut o_comp = {components, off, n * QG_NWALKREWARD * 4};         off += pin_align(o_comp.bytes);
+    int rc = pin_reserve(s, off);
+    if (rc == QG_OK) rc = pin_actions_in(s, actions, w->d_actions);
+    if (rc == QG_OK) rc = qg_walk_step_device(w, w->d_actions, w->d_obs, w->d_reward, w->d_done, components ? w->d_comps : nullptr, s->stream);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_obs, w->d_obs);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_rew, w->d_reward);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_done, w->d_done);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_comp, w->d_comps);
     if (rc != QG_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(obs, w->d_obs, n * QG_NSENSOR * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipMemcpyAsync(reward, w->d_reward, n * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipMemcpyAsync(done, w->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    if (components) HIP_TRY(hipMemcpyAsync(components, w->d_comps, n * QG_NWALKREWARD * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
     HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    pin_out_finish(s, o_obs); pin_out_finish(s, o_rew); pin_out_finish(s, o_done); pin_out_finish(s, o_comp);
     return QG_OK;
 }
 
@@ -1016,15 +1069,22 @@ extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *rew
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
     size_t n = (size_t)s->n, width = (size_t)p->kp.window * QG_PO_FRAME;
-    HIP_TRY(hipMemcpyAsync(w->d_actions, actions, n * 12 * 4, hipMemcpyHostToDevice, s->stream), QG_ERR_DEVICE);
-    int rc = qg_po_step_device(p, w->d_actions, p->d_out, w->d_reward, w->d_done, components ? w->d_comps : nullptr,
-                               terminal_obs ? p->d_term : nullptr, s->stream);
+    size_t off = pin_align(n * QG_NU * sizeof(float));
+    PinOut o_obs = {obs, off, n * width * 4};                          off += pin_align(o_obs.bytes);
+    PinOut o_rew = {reward, off, n * 4};                               off += pin_align(o_rew.bytes);
+    PinOut o_done = {done, off, n};                                    off += pin_align(o_done.bytes);
+    PinOut o_comp = {components, off, n * QG_NWALKREWARD * 4};         off += pin_align(o_comp.bytes);
+    int rc = pin_reserve(s, off);
+    if (rc == QG_OK) rc = pin_actions_in(s, actions, w->d_actions);
+    if (rc == QG_OK) rc = qg_po_step_device(p, w->d_actions, p->d_out, w->d_reward, w->d_done, components ? w->d_comps : nullptr,
+                                            terminal_obs ? p->d_term : nullptr, s->stream);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_obs, p->d_out);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_rew, w->d_reward);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_done, w->d_done);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_comp, w->d_comps);
     if (rc != QG_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(obs, p->d_out, n * width * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipMemcpyAsync(reward, w->d_reward, n * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipMemcpyAsync(done, w->d_done, n, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    if (components) HIP_TRY(hipMemcpyAsync(components, w->d_comps, n * QG_NWALKREWARD * 4, hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
     HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    pin_out_finish(s, o_obs); pin_out_finish(s, o_rew); pin_out_finish(s, o_done); pin_out_finish(s, o_comp);
     if (terminal_obs) {
         // the terminal stacks only exist for envs that finished: the [n][obs_dim] transfer (4.3 MB at 4096 envs and window 10 -- as much
         // as the observation itself) is skipped on the steps where none did
