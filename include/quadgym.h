@@ -181,6 +181,11 @@ int qg_step_device_packed(qg_sim *sim, const float *actions, float *packed, void
 /* Snapshot / restore of data.qpos, qvel, act, ctrl and the substep counter
  * (host pointers; any may be NULL).  Used by the parity tests and checkpoints. */
 int qg_get_state(qg_sim *sim, float *qpos, float *qvel, float *act, float *ctrl, int32_t *nstep);
+/* qg_step followed by qg_get_state in ONE call and one synchronisation (any of the state pointers may be NULL): what an env that
+ * mirrors the state on the host after every step needs -- the reference's `env.data`, which user reward / termination callables
+ * read (quadruped.py:170-178). */
+int qg_step_mirror(qg_sim *sim, const float *actions, float *obs, float *reward, uint8_t *done, float *reward_components, float *qpos,
+                   float *qvel, float *act, float *ctrl, int32_t *nstep);
 int qg_set_state(qg_sim *sim, const float *qpos, const float *qvel, const float *act, const float *ctrl,
                  const int32_t *nstep);
 

@@ -168,6 +168,7 @@ def load_library():
     lib.qg_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.qg_step_device_packed.argtypes = [vp, vp, vp, vp]
     lib.qg_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.qg_step_mirror.argtypes = [vp] * 11
     lib.qg_set_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.qg_time_step_kernel.argtypes = [vp, vp, vp, C.c_int32, C.POINTER(C.c_float)]
     lib.qg_set_track_ctrl.argtypes = [vp, C.c_int32]
@@ -210,7 +211,7 @@ def load_library():
 EXPORTS = (
     "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
-    "qg_step_device_packed", "qg_get_state", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_debug_phase_times", "qg_set_task", "qg_get_task",
+    "qg_step_device_packed", "qg_get_state", "qg_step_mirror", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_debug_phase_times", "qg_set_task", "qg_get_task",
     "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
     "qg_comm_unique_id", "qg_comm_create", "qg_comm_destroy", "qg_comm_rollout", "qg_comm_synchronize",
     "qg_walk_default_params", "qg_walk_create", "qg_walk_destroy", "qg_walk_set_commands", "qg_walk_reset", "qg_walk_step",

@@ -175,7 +175,7 @@ extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *mode
     ALLOC(s->d_obs, n * (QG_NSENSOR + 2) * sizeof(float));
     ALLOC(s->d_reward, n * sizeof(float));
     ALLOC(s->d_comps, n * QG_NREWARD * sizeof(float));
-    ALLOC(s->d_stage, n * QG_NQ * sizeof(float));
+    ALLOC(s->d_stage, n * (QG_NQ + QG_NV + 2 * QG_NU) * sizeof(float));     // all four state fields side by side (qg_get_state)
     ALLOC(s->d_done, n);
     ALLOC(s->d_mask, n);
 #undef ALLOC
@@ -415,16 +415,6 @@ extern "C" int qg_step(qg_sim *s, const float *actions, float *obs, float *rewar
     return QG_OK;
 }
 
-static int copy_out(qg_sim *s, const float *field_major, float *host, int w) {
-    if (!host) return QG_OK;
-    int total = s->n * w, threads = 256;
-    hipLaunchKernelGGL(qg_transpose_out, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, field_major, s->d_stage, s->n, w);
-    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
-    HIP_TRY(hipMemcpyAsync(host, s->d_stage, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s->stream), QG_ERR_DEVICE);
-    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
-    return QG_OK;
-}
-
 static int copy_in(qg_sim *s, const float *host, float *field_major, int w) {
     if (!host) return QG_OK;
     int total = s->n * w, threads = 256;
@@ -435,16 +425,77 @@ static int copy_in(qg_sim *s, const float *host, float *field_major, int w) {
     return QG_OK;
 }
 
+// State snapshot, part 1: where the five outputs land in the page-locked arena (from `off` on); part 2: the four transposes into their
+// own regions of the staging buffer and every transfer, enqueued on the library's stream (no synchronisation in here).
+struct StateOut { PinOut o[5]; };
+static size_t state_out_layout(qg_sim *s, float *qpos, float *qvel, float *act, float *ctrl, int32_t *nstep, size_t off, StateOut &so) {
+    const size_t n = (size_t)s->n;
+    float *dst[4] = {qpos, qvel, act, ctrl};
+    const int w[4] = {QG_NQ, QG_NV, QG_NU, QG_NU};
+    for (int f = 0; f < 4; f++) { so.o[f] = {dst[f], off, n * w[f] * sizeof(float)}; off += pin_align(so.o[f].bytes); }
+    so.o[4] = {nstep, off, n * sizeof(int32_t)};
+    return off + pin_align(so.o[4].bytes);
+}
+static int state_out_enqueue(qg_sim *s, const StateOut &so) {
+    const size_t n = (size_t)s->n;
+    const float *src[4] = {s->st.qpos, s->st.qvel, s->st.act, s->st.ctrl};
+    const int w[4] = {QG_NQ, QG_NV, QG_NU, QG_NU};
+    size_t soff = 0;
+    int rc;
+    for (int f = 0; f < 4; f++) {
+        float *stage = s->d_stage + soff;
+        soff += n * w[f];
+        if (!so.o[f].user) continue;
+        const int total = s->n * w[f], threads = 256;
+        hipLaunchKernelGGL(qg_transpose_out, dim3((total + threads - 1) / threads), dim3(threads), 0, s->stream, src[f], stage, s->n, w[f]);
+        HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+        if ((rc = pin_out_enqueue(s, so.o[f], stage)) != QG_OK) return rc;
+    }
+    return pin_out_enqueue(s, so.o[4], s->st.nstep);
+}
+
 extern "C" int qg_get_state(qg_sim *s, float *qpos, float *qvel, float *act, float *ctrl, int32_t *nstep) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps may be in flight on a caller's stream
-    int rc;
-    if ((rc = copy_out(s, s->st.qpos, qpos, QG_NQ)) != QG_OK) return rc;
-    if ((rc = copy_out(s, s->st.qvel, qvel, QG_NV)) != QG_OK) return rc;
-    if ((rc = copy_out(s, s->st.act, act, QG_NU)) != QG_OK) return rc;
-    if ((rc = copy_out(s, s->st.ctrl, ctrl, QG_NU)) != QG_OK) return rc;
-    if (nstep) HIP_TRY(hipMemcpy(nstep, s->st.nstep, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    // every transfer enqueued, ONE synchronisation (five synchronised round trips made the single-env facade's mirror of the state
+    // 120 us of a 160 us step)
+    StateOut so;
+    int rc = pin_reserve(s, state_out_layout(s, qpos, qvel, act, ctrl, nstep, 0, so));
+    if (rc == QG_OK) rc = state_out_enqueue(s, so);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    for (int f = 0; f < 5; f++) pin_out_finish(s, so.o[f]);
+    return QG_OK;
+}
+
+// qg_step and qg_get_state in one call and one synchronisation: what an env that mirrors the state on the host after every step
+// (the reference's `env.data`, read by user reward / termination callables) needs.
+extern "C" int qg_step_mirror(qg_sim *s, const float *actions, float *obs, float *reward, uint8_t *done, float *comps, float *qpos, float *qvel,
+                              float *act, float *ctrl, int32_t *nstep) {
+    if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step_mirror: null argument");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
+    size_t n = (size_t)s->n;
+    size_t off = pin_align(n * QG_NU * sizeof(float));
+    PinOut o_obs = {obs, off, n * s->obs_dim * sizeof(float)};       off += pin_align(o_obs.bytes);
+    PinOut o_rew = {reward, off, n * sizeof(float)};                   off += pin_align(o_rew.bytes);
+    PinOut o_done = {done, off, n};                                    off += pin_align(o_done.bytes);
+    PinOut o_comp = {comps, off, n * QG_NREWARD * sizeof(float)};      off += pin_align(o_comp.bytes);
+    StateOut so;
+    off = state_out_layout(s, qpos, qvel, act, ctrl, nstep, off, so);
+    int rc = pin_reserve(s, off);
+    if (rc == QG_OK) rc = pin_actions_in(s, actions, s->d_actions);
+    if (rc == QG_OK) rc = launch_step(s, s->d_actions, s->d_obs, s->d_reward, s->d_done, comps ? s->d_comps : nullptr, nullptr, s->stream);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_obs, s->d_obs);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_rew, s->d_reward);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_done, s->d_done);
+    if (rc == QG_OK) rc = pin_out_enqueue(s, o_comp, s->d_comps);
+    if (rc == QG_OK) rc = state_out_enqueue(s, so);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    pin_out_finish(s, o_obs); pin_out_finish(s, o_rew); pin_out_finish(s, o_done); pin_out_finish(s, o_comp);
+    for (int f = 0; f < 5; f++) pin_out_finish(s, so.o[f]);
     return QG_OK;
 }
 

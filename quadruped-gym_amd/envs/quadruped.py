@@ -132,8 +132,8 @@ class QuadrupedEnv(EnvBase):
         lo, hi = self.action_space.low, self.action_space.high
         applied = np.minimum(np.maximum(np.asarray(action, dtype=np.float64), lo), hi)
         self._push_if_edited()
-        sensed = self._sim.step(applied.astype(np.float32)[None])[0]
-        self._pull()
+        (sensed, _, _, _), state = self._sim.step_mirror(applied.astype(np.float32)[None])    # one launch, one synchronisation
+        self._pull(state)
         h = self.model.opt.timestep
         for _ in range(self.frame_skip):                    # the engine's f64 clock: one addition per substep
             self.data.time += h
@@ -160,8 +160,8 @@ class QuadrupedEnv(EnvBase):
             self._sim = None
 
     # -- host mirror <-> device state -----------------------------------------------------------------
-    def _pull(self):
-        qpos, qvel, act, ctrl, nstep = self._sim.get_state()
+    def _pull(self, state=None):
+        qpos, qvel, act, ctrl, nstep = state if state is not None else self._sim.get_state()
         self.data.qpos[:] = qpos[0]
         self.data.qvel[:] = qvel[0]
         self.data.act[:] = act[0]

@@ -251,10 +251,10 @@ class QuadrupedVecEnv(_VecEnvBase):
     def step_async(self, actions):
         self._actions = np.asarray(actions, dtype=np.float32)
 
-    def _eval_callables(self, obs):
+    def _eval_callables(self, obs, state=None):
         """Host evaluation of the Python callables over ``self.data``; returns (components {name: [N]}, done [N])."""
         n = self.num_envs
-        qpos, qvel, act, ctrl, nstep = self._sim.get_state()
+        qpos, qvel, act, ctrl, nstep = state if state is not None else self._sim.get_state()
         self.data.load(qpos, qvel, act, ctrl, nstep, obs, self.model.opt.timestep)
         comps = {name: np.zeros(n) for name in self._host_rewards}
         done = np.zeros(n, bool)
@@ -278,11 +278,15 @@ class QuadrupedVecEnv(_VecEnvBase):
     def step_wait(self):
         self._sync_task()
         host = bool(self._host_rewards or self._host_terms)
-        obs, rew, done, comps = self._sim.step(self._actions, want_components=True)
+        state = None
+        if host:                                            # step + state snapshot in one call and one synchronisation
+            (obs, rew, done, comps), state = self._sim.step_mirror(self._actions, want_components=True)
+        else:
+            obs, rew, done, comps = self._sim.step(self._actions, want_components=True)
         names = _REWARD_BUILTINS
         host_comps = {}
         if host:
-            host_comps, host_done = self._eval_callables(obs)
+            host_comps, host_done = self._eval_callables(obs, state)
             rew = rew.astype(np.float64)
             for v in host_comps.values():
                 rew = rew + v

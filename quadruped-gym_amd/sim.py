@@ -70,6 +70,25 @@ class BatchedSim:
                                 comps.ctypes.data if want_components else None), "qg_step")
         return obs, rew, done.astype(bool), comps
 
+    def step_mirror(self, actions, want_components: bool = False):
+        """``step`` and ``get_state`` in one call and one synchronisation: ``(obs, rew, done, comps), (qpos, qvel, act, ctrl, nstep)``."""
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.n, NU):
+            raise ValueError(f"actions must have shape ({self.n}, {NU}), got {a.shape}")
+        obs = np.empty((self.n, self.obs_dim), np.float32)
+        rew = np.empty(self.n, np.float32)
+        done = np.empty(self.n, np.uint8)
+        comps = np.empty((self.n, NREWARD), np.float32) if want_components else None
+        qpos = np.empty((self.n, NQ), np.float32)
+        qvel = np.empty((self.n, NV), np.float32)
+        act = np.empty((self.n, NU), np.float32)
+        ctrl = np.empty((self.n, NU), np.float32)
+        nstep = np.empty(self.n, np.int32)
+        check(self._lib.qg_step_mirror(self._h, a.ctypes.data, obs.ctypes.data, rew.ctypes.data, done.ctypes.data,
+                                       comps.ctypes.data if want_components else None, qpos.ctypes.data, qvel.ctypes.data, act.ctypes.data,
+                                       ctrl.ctypes.data, nstep.ctypes.data), "qg_step_mirror")
+        return (obs, rew, done.astype(bool), comps), (qpos, qvel, act, ctrl, nstep)
+
     # -- zero-copy forms on torch (ROCm) tensors ---------------------------------------------------
     def _stream_ptr(self, stream):
         import torch
