@@ -34,6 +34,7 @@ struct qg_sim {
     KState st;
     // staging for the host-pointer entry points
     float *d_actions, *d_obs, *d_reward, *d_comps, *d_stage;
+    int32_t caller_inflight;  // a device-pointer step has been enqueued on a caller's stream since the last device-wide wait
     uint8_t *h_pin;           // page-locked staging of the host-pointer entry points (see pin_reserve)
     size_t h_pin_cap;
     uint8_t *d_done, *d_mask;
@@ -268,6 +269,7 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.env_index_base = s->env_index_base;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     const int emap = effective_mapping(s);
+    if (stream != s->stream) s->caller_inflight = 1;
     if (po && !(walk && emap == QG_MAP_LINK)) return fail(QG_ERR_ARG, "launch_step: the fused observation pack needs the one-link-per-lane walking kernel");
     if (walk && emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
@@ -392,10 +394,19 @@ static void pin_out_finish(qg_sim *s, const PinOut &o) {
     if (o.user && o.bytes <= QG_PIN_MAX_BYTES) memcpy(o.user, s->h_pin + o.off, o.bytes);
 }
 
+// The host-pointer steps must not overtake device-pointer steps still in flight on a caller's stream; a device-wide wait is only
+// needed if one has been enqueued since the last one (the library's own stream is synchronised at the end of every host-pointer call).
+static int wait_for_caller_streams(qg_sim *s) {
+    if (!s->caller_inflight) return QG_OK;
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    s->caller_inflight = 0;
+    return QG_OK;
+}
+
 extern "C" int qg_step(qg_sim *s, const float *actions, float *obs, float *reward, uint8_t *done, float *comps) {
     if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step: null argument");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
-    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
+    { int rc0 = wait_for_caller_streams(s); if (rc0 != QG_OK) return rc0; }
     size_t n = (size_t)s->n;
     size_t off = pin_align(n * QG_NU * sizeof(float));
     PinOut o_obs = {obs, off, n * s->obs_dim * sizeof(float)};       off += pin_align(o_obs.bytes);
@@ -475,7 +486,7 @@ extern "C" int qg_step_mirror(qg_sim *s, const float *actions, float *obs, float
                               float *act, float *ctrl, int32_t *nstep) {
     if (!s || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_step_mirror: null argument");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
-    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
+    { int rc0 = wait_for_caller_streams(s); if (rc0 != QG_OK) return rc0; }
     size_t n = (size_t)s->n;
     size_t off = pin_align(n * QG_NU * sizeof(float));
     PinOut o_obs = {obs, off, n * s->obs_dim * sizeof(float)};       off += pin_align(o_obs.bytes);
@@ -952,7 +963,7 @@ extern "C" int qg_walk_step(qg_walk *w, const float *actions, float *obs, float 
     if (!w || !actions || !obs || !reward || !done) return fail(QG_ERR_ARG, "qg_walk_step: null argument");
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
-    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
+    { int rc0 = wait_for_caller_streams(s); if (rc0 != QG_OK) return rc0; }
     size_t n = (size_t)s->n;
     size_t off = pin_align(n * QG_NU * sizeof(float));
     PinOut o_obs = {obs, off, n * QG_NSENSOR * 4};                     off += pin_align(o_obs.bytes);
@@ -1118,7 +1129,7 @@ extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *rew
     qg_walk *w = p->walk;
     qg_sim *s = w->sim;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
-    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // device-pointer steps may be in flight on a caller's stream
+    { int rc0 = wait_for_caller_streams(s); if (rc0 != QG_OK) return rc0; }
     size_t n = (size_t)s->n, width = (size_t)p->kp.window * QG_PO_FRAME;
     size_t off = pin_align(n * QG_NU * sizeof(float));
     PinOut o_obs = {obs, off, n * width * 4};                          off += pin_align(o_obs.bytes);

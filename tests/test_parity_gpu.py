@@ -520,6 +520,32 @@ def test_reset_is_ordered_after_steps_on_a_side_stream():
     sim.close()
 
 
+def test_host_step_is_ordered_after_steps_on_a_side_stream():
+    """The host-pointer step only pays a device-wide wait when a device-pointer step has been enqueued on a caller's stream since the
+    last one -- and then it must: 150 steps queued on a side stream followed at once by a host step give the state of 151 steps in
+    order (a twin batch stepped through the host entry point only is the reference; same kernel, same inputs: bit-identical)."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    n = 32768
+    a, b = BatchedSim(n), BatchedSim(n)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    acts_h = np.random.default_rng(3).uniform(-1, 1, (n, 12)).astype(np.float32)
+    acts = torch.from_numpy(acts_h).to(dev)
+    packed = torch.empty((n, 35), device=dev)
+    torch.cuda.synchronize()
+    for _ in range(150):                          # ~4 ms of queued kernels: the host gets far ahead of the device
+        a.step_device_packed(acts, packed, stream=side)
+    obs_a, rew_a, done_a, _ = a.step(acts_h)      # must wait for the 150
+    for _ in range(150):
+        b.step(acts_h)
+    obs_b, rew_b, done_b, _ = b.step(acts_h)
+    assert np.array_equal(obs_a, obs_b) and np.array_equal(rew_a, rew_b) and np.array_equal(done_a, done_b)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
 def test_masked_reset_keeps_the_batch_seed(oracle):
     """The seed keys the reset streams of every env (auto-resets included); a masked reset must not re-key the batch: it
     draws from the seed of the last whole-batch reset, whatever seed argument it is given."""
