@@ -23,6 +23,9 @@
  * for ALL work on the handle's device (hipDeviceSynchronize), runs on the library's own stream and
  * returns when it has completed -- it can therefore follow device-pointer steps on any stream
  * without further synchronisation, and must not be called while a stream is being captured.
+ * (The host-pointer steps skip that device-wide wait when no device-pointer call of this handle
+ * has gone to a caller's stream since the last one: their own stream is synchronised at the end
+ * of every call, so there is nothing to wait for.)
  *
  * Layouts at the boundary (row-major, env-major -- what NumPy / torch hand over):
  *   actions  [n_envs][12] f32      obs   [n_envs][obs_dim] f32
