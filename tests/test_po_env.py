@@ -188,3 +188,50 @@ def test_po_fused_launch_equals_separate_launches(window, modified, monkeypatch)
     for x, y in zip(s1, s2):
         assert np.array_equal(x, y)
     fused.close(); split.close()
+
+
+@pytest.mark.gpu
+def test_po_step_replays_from_a_hipgraph_like_eager():
+    """Nothing in the fused partially observable step lives on the host between launches (ring positions, call counters, episode
+    counters, command streams: all device state), so a hipGraph of env-steps can be replayed: 8 captured steps x 12 replays -- through
+    auto-resets and re-drawn commands -- leave the same observations, rewards, dones and simulator state as 96 eager steps of a twin."""
+    import torch
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
+    n, G = 200, 8
+    kw = dict(obs_window=10, frame_skip=4, max_time=0.2, random_init=True, random_controls=True, device_commands=True, seed=5,
+              reset_options={"min_speed": 0.1, "max_speed": 0.4})
+    a_env, b_env = POWalkingQuadrupedVecEnv(n, **kw), POWalkingQuadrupedVecEnv(n, **kw)
+    a_env.reset(); b_env.reset()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    acts = [torch.rand((n, 12), generator=gen, device=dev) * 2 - 1 for _ in range(G)]
+    mk = lambda: (torch.empty((n, a_env.obs_dim), device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev, dtype=torch.uint8))
+    obs_a, rew_a, done_a = mk()
+    obs_b, rew_b, done_b = mk()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):                         # one pass outside the capture (lazy initialisation), mirrored on the twin
+        for g in range(G):
+            a_env.step_tensor(acts[g], obs_a, rew_a, done_a, stream=side)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for g in range(G):
+        b_env.step_tensor(acts[g], obs_b, rew_b, done_b)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for g in range(G):
+            a_env.step_tensor(acts[g], obs_a, rew_a, done_a, stream=torch.cuda.current_stream(dev))
+    finished = 0
+    for rep in range(12):                                 # 0.2 s / 8 ms = 25 steps per episode: several auto-resets
+        graph.replay()
+        for g in range(G):
+            b_env.step_tensor(acts[g], obs_b, rew_b, done_b)
+        torch.cuda.synchronize()
+        assert torch.equal(obs_a, obs_b) and torch.equal(done_a, done_b), rep
+        assert torch.equal(torch.nan_to_num(rew_a, nan=-1e9), torch.nan_to_num(rew_b, nan=-1e9)), rep
+        finished += int(done_a.sum())
+    for x, y in zip(a_env._sim.get_state(), b_env._sim.get_state()):
+        assert np.array_equal(x, y)
+    (v1, h1), (v2, h2) = a_env.commands(), b_env.commands()
+    assert np.array_equal(v1, v2) and np.array_equal(h1, h2)
+    a_env.close(); b_env.close()
