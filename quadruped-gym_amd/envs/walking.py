@@ -15,6 +15,7 @@ from ..model.loader import load_model
 from ..sim import BatchedSim
 from .quadruped import ModelView
 from .infos import LazyInfos
+from .vec_env import HAVE_SB3, _VecEnvBase
 from .spaces import Box
 
 REWARD_KEYS = ["alive_bonus", "control_cost", "progress_direction_reward_local", "progress_speed_cost_local",
@@ -43,7 +44,7 @@ def sample_command(options=None, uniform=None):
     return (speed * np.cos(alpha), speed * np.sin(alpha)), (np.cos(theta), np.sin(theta))
 
 
-class WalkingQuadrupedVecEnv:
+class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that package is importable (what `PPO(..., env)` checks for), else object
     """N walking robots; SB3 VecEnv calling convention (replaces ``SubprocVecEnv([make_env]*N)`` at
     ``src/train_quadruped.py:50``).  ``infos[i]`` is the reward-component dict the reference returns as
     ``info`` (``walking_quad.py:146-148,419``), which ``RewardCallback`` reads (``train_quadruped.py:86-97``)."""
@@ -87,6 +88,8 @@ class WalkingQuadrupedVecEnv:
             check(self._lib.qg_walk_set_command_sampler(self._w, C.byref(sampler)), "qg_walk_set_command_sampler")
         self.action_space = Box(low=-1.0, high=1.0, shape=(12,), dtype=np.float32)
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(33,), dtype=np.float32)
+        if HAVE_SB3:  # pragma: no cover - stable_baselines3 is absent from the build image
+            _VecEnvBase.__init__(self, self.num_envs, self.observation_space, self.action_space)
         self.velocity = np.zeros((self.num_envs, 2), np.float32)
         self.heading = np.zeros((self.num_envs, 2), np.float32)
         self.dt = qg_model.timestep * self.frame_skip
@@ -272,6 +275,8 @@ class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
         self._po = h
         self.obs_dim = int(self._lib.qg_po_obs_dim(self._po))
         self.observation_space = Box(low=-np.inf, high=np.inf, shape=(self.obs_dim,), dtype=np.float32)   # po_walking_quad.py:27
+        if HAVE_SB3:  # pragma: no cover
+            _VecEnvBase.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
     def reset(self):
         obs = np.empty((self.num_envs, self.obs_dim), np.float32)
