@@ -10,6 +10,22 @@ terminal observations) are captured, not copied per env.
 """
 from __future__ import annotations
 
+import types
+
+# what `infos[i]` is for an env that did not finish when the env was built with infos_mode="finished": one shared, read-only, empty
+# mapping (`.get`, `in`, iteration, `.copy()` behave; assignment raises instead of leaking into every other env's info)
+NO_INFO = types.MappingProxyType({})
+
+
+def finished_only_infos(n: int, finished: dict) -> list:
+    """Plain list for ``infos_mode="finished"``: full dicts for the envs in ``finished`` (index -> dict), ``NO_INFO`` elsewhere.
+    SB3's rollout collection calls ``info.get("episode")`` on EVERY element every step, which would materialise every lazily built
+    dict (~1 us each); with this mode that loop runs over one shared empty mapping and only finished envs carry content."""
+    infos = [NO_INFO] * n
+    for i, d in finished.items():
+        infos[i] = d
+    return infos
+
 
 class LazyInfos(list):
     """``list`` of per-env info dicts; ``make(i)`` builds the dict of env ``i`` the first time it is asked for."""

@@ -34,7 +34,7 @@ import numpy as np
 from .. import _abi
 from ..model.loader import load_model
 from ..sim import BatchedSim
-from .infos import LazyInfos
+from .infos import LazyInfos, finished_only_infos
 from .quadruped import ModelView
 from .spaces import Box
 
@@ -146,9 +146,12 @@ class QuadrupedVecEnv(_VecEnvBase):
     def __init__(self, num_envs: int, model_path: str | None = "builtin", max_time: float = 10.0, frame_skip: int = 4,
                  reward_fns: dict | None = None, termination_fns: dict | None = None, use_default_termination: bool = True,
                  obs_mode: int = _abi.OBS_FULL, random_init: bool = False, device: int = 0, env_index_base: int = 0,
-                 seed: int = 0, callable_mode: str = "per_env"):
+                 seed: int = 0, callable_mode: str = "per_env", infos_mode: str = "lazy"):
         if callable_mode not in ("per_env", "batched"):
             raise ValueError("callable_mode must be 'per_env' or 'batched'")
+        if infos_mode not in ("lazy", "finished"):
+            raise ValueError("infos_mode must be 'lazy' or 'finished'")
+        self.infos_mode = infos_mode
         qg_model, layout = load_model(model_path)
         self.model = ModelView(qg_model, layout)
         self.num_envs = int(num_envs)
@@ -312,7 +315,8 @@ class QuadrupedVecEnv(_VecEnvBase):
             if e:
                 info.update(e)
             return info
-        infos = LazyInfos(self.num_envs, make)
+        infos = (finished_only_infos(self.num_envs, {i: make(i) for i in extra}) if self.infos_mode == "finished"
+                 else LazyInfos(self.num_envs, make))
         if host and finished.size:
             self._sim.reset(mask=done.astype(np.uint8), flags=self._reset_flags)    # draws from the batch's own streams
         if finished.size:

@@ -14,7 +14,7 @@ from .._abi import NWALKREWARD, QgWalkParams, check
 from ..model.loader import load_model
 from ..sim import BatchedSim
 from .quadruped import ModelView
-from .infos import LazyInfos
+from .infos import LazyInfos, finished_only_infos
 from .vec_env import HAVE_SB3, _VecEnvBase
 from .spaces import Box
 
@@ -44,6 +44,21 @@ def sample_command(options=None, uniform=None):
     return (speed * np.cos(alpha), speed * np.sin(alpha)), (np.cos(theta), np.sin(theta))
 
 
+def _component_infos(n, comps, extra, mode="lazy"):
+    """``infos`` of a walking step: per env the reward-component dict the reference returns as ``info`` (walking_quad.py:419), plus
+    the SB3 entries of the envs in ``extra``; built on first access (see envs/infos.py), or -- ``mode="finished"`` -- only for the
+    envs that finished."""
+    def make(i):
+        d = dict(zip(REWARD_KEYS, comps[i].tolist()))
+        e = extra.get(i)
+        if e:
+            d.update(e)
+        return d
+    if mode == "finished":
+        return finished_only_infos(n, {i: make(i) for i in extra})
+    return LazyInfos(n, make)
+
+
 class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that package is importable (what `PPO(..., env)` checks for), else object
     """N walking robots; SB3 VecEnv calling convention (replaces ``SubprocVecEnv([make_env]*N)`` at
     ``src/train_quadruped.py:50``).  ``infos[i]`` is the reward-component dict the reference returns as
@@ -53,7 +68,11 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
 
     def __init__(self, num_envs, settling_time=0, random_controls=False, random_init=False, reset_options=None,
                  model_path="builtin", max_time=10.0, frame_skip=4, device=0, env_index_base=0, seed=0, walk_params=None,
-                 device_commands=False, auto_reset=True, use_default_termination=True):
+                 device_commands=False, auto_reset=True, use_default_termination=True, infos_mode="lazy"):
+        if infos_mode not in ("lazy", "finished"):
+            raise ValueError("infos_mode must be 'lazy' (every env's component dict, built when touched) or 'finished' (content "
+                             "for the envs that finished only; `last_components` holds every env's components as one array)")
+        self.infos_mode = infos_mode
         qg_model, layout = load_model(model_path)
         self.model = ModelView(qg_model, layout)
         self.num_envs = int(num_envs)
@@ -140,7 +159,7 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
         if self.auto_reset:
             for i in np.nonzero(dones)[0]:
                 extra[int(i)] = {"terminal_observation": obs[i].copy(), "TimeLimit.truncated": False}
-        infos = _component_infos(n, comps, extra)
+        infos = _component_infos(n, comps, extra, self.infos_mode)
         if self.auto_reset and dones.any():
             obs = obs.copy()
             obs[dones] = 0.0
@@ -177,18 +196,6 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
     def seed(self, seed=None):
         self._seed = 0 if seed is None else int(seed)
         return [self._seed + i for i in range(self.num_envs)]
-
-
-def _component_infos(n, comps, extra):
-    """``infos`` of a walking step: per env the reward-component dict the reference returns as ``info`` (walking_quad.py:419), plus
-    the SB3 entries of the envs in ``extra``; built on first access (see envs/infos.py)."""
-    def make(i):
-        d = dict(zip(REWARD_KEYS, comps[i].tolist()))
-        e = extra.get(i)
-        if e:
-            d.update(e)
-        return d
-    return LazyInfos(n, make)
 
     def get_attr(self, attr_name, indices=None):
         idx = range(self.num_envs) if indices is None else ([indices] if isinstance(indices, int) else indices)
@@ -304,7 +311,7 @@ class POWalkingQuadrupedVecEnv(WalkingQuadrupedVecEnv):
         if self.auto_reset:
             for i in np.nonzero(dones)[0]:
                 extra[int(i)] = {"terminal_observation": term[i].copy(), "TimeLimit.truncated": False}
-        infos = _component_infos(n, comps, extra)
+        infos = _component_infos(n, comps, extra, self.infos_mode)
         if self.auto_reset and dones.any() and self.random_controls:
             self._resample(np.nonzero(dones)[0])
         self.last_components = comps

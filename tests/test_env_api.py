@@ -317,3 +317,35 @@ def test_lazy_infos_is_a_list_of_dicts_built_on_demand():
     assert infos == plain and not (infos != plain) and list(reversed(infos))[0]["i"] == 5
     assert pickle.loads(pickle.dumps(infos)) == plain and copy.deepcopy(infos) == plain and type(copy.deepcopy(infos)) is list
     assert repr(infos) == repr(plain) and infos.copy() == plain and plain[3] in infos
+
+
+@pytest.mark.gpu
+def test_walking_vec_envs_carry_the_whole_vecenv_protocol():
+    """SB3's VecEnv is abstract: reset, step_async, step_wait, close, get_attr, set_attr, env_method, env_is_wrapped must all exist
+    on the walking envs too (a subclass of it where SB3 is importable), and `infos_mode="finished"` hands SB3's per-step
+    `info.get("episode")` loop one shared empty mapping for the envs that are still running."""
+    from quadruped_gym_amd.envs.infos import NO_INFO
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv, REWARD_KEYS, WalkingQuadrupedVecEnv
+    for cls, kw in ((WalkingQuadrupedVecEnv, {}), (POWalkingQuadrupedVecEnv, {"obs_window": 3})):
+        env = cls(6, max_time=0.024, infos_mode="finished", **kw)
+        for name in ("reset", "step_async", "step_wait", "step", "close", "get_attr", "set_attr", "env_method", "env_is_wrapped", "seed"):
+            assert callable(getattr(env, name)), name
+        assert env.get_attr("num_envs") == [6] * 6 and env.get_attr("frame_skip", indices=2) == [4]
+        assert env.env_is_wrapped(object) == [False] * 6 and len(env.seed(3)) == 6
+        env.set_attr("some_tag", 7)
+        assert env.env_method("get_attr", "some_tag", indices=[0]) == [[7] * 6]
+        env.reset()
+        a = np.zeros((6, 12), np.float32)
+        seen_done = False
+        for _ in range(4):                                   # time limit 0.024 s = 3 env-steps
+            obs, rew, dones, infos = env.step(a)
+            assert type(infos) is list and len(infos) == 6
+            for i in range(6):
+                if dones[i]:
+                    seen_done = True
+                    assert set(REWARD_KEYS) <= set(infos[i]) and "terminal_observation" in infos[i] and infos[i]["TimeLimit.truncated"] is False
+                else:
+                    assert infos[i] is NO_INFO and infos[i].get("episode") is None and len(infos[i]) == 0
+            assert env.last_components.shape == (6, 11)
+        assert seen_done
+        env.close()
