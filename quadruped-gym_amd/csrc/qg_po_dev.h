@@ -36,12 +36,34 @@ struct KPoState {
 // division (~20 instructions, six times per frame on lanes that have nothing else to do); every argument is a guarded, O(1) sum of squares
 __device__ __forceinline__ float po_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 
+// atan2 / asin of the frame's Euler angles and command heading: a ~25-instruction form (the math library's are ~70 each, evaluated on
+// lanes that have nothing else to do).  |y| / |x| reduced to [0, 1], then Cephes' single-precision reduction at tan(pi/8) and its
+// degree-7 odd polynomial (abs. error < 3e-7 rad over the plane, checked against numpy in tests/test_po_env.py); asin(v) = atan2(v,
+// sqrt((1 - v)(1 + v))).
+__device__ __forceinline__ float po_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const bool big = a > 0.41421356237f;
+    const float t = big ? (a - 1.f) * __builtin_amdgcn_rcpf(a + 1.f) : a;
+    const float z = t * t;
+    const float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    float r = fmaf(p * z, t, t) + (big ? 0.78539816339f : 0.f);
+    r = ay > ax ? 1.57079632679f - r : r;
+    r = x < 0.f ? 3.14159265359f - r : r;
+    r = mx == 0.f ? 0.f : r;
+    return __builtin_copysignf(r, y);
+}
+__device__ __forceinline__ float po_asin(float v) {
+    return po_atan2(v, __builtin_amdgcn_sqrtf(fmaxf((1.f - v) * (1.f + v), 0.f)));
+}
+
 __device__ __forceinline__ void po_euler(float w, float x, float y, float z, float &roll, float &pitch, float &yaw) {
     float inv = po_rsqrt(w * w + x * x + y * y + z * z);
     w *= inv; x *= inv; y *= inv; z *= inv;
-    roll = atan2f(2.f * (w * x + y * z), 1.f - 2.f * (x * x + y * y));
-    pitch = asinf(fminf(fmaxf(2.f * (w * y - z * x), -1.f), 1.f));
-    yaw = atan2f(2.f * (w * z + x * y), 1.f - 2.f * (y * y + z * z));
+    roll = po_atan2(2.f * (w * x + y * z), 1.f - 2.f * (x * x + y * y));
+    pitch = po_asin(fminf(fmaxf(2.f * (w * y - z * x), -1.f), 1.f));
+    yaw = po_atan2(2.f * (w * z + x * y), 1.f - 2.f * (y * y + z * z));
 }
 
 
@@ -132,7 +154,7 @@ __device__ __forceinline__ void po_frame_env(const KPoParams &P, const KPoState 
     }
     float roll, pitch, yaw;
     po_euler(qw, qx, qy, qz, roll, pitch, yaw);
-    const float theta = atan2f(hy, hx);                               // control_inputs.py:69-73
+    const float theta = po_atan2(hy, hx);                               // control_inputs.py:69-73
     fr[0] = gx; fr[1] = gy; fr[2] = gz; fr[3] = ax; fr[4] = ay; fr[5] = az;
     fr[6] = roll; fr[7] = pitch; fr[8] = yaw;
     fr[9] = s[30]; fr[10] = s[31];
@@ -267,8 +289,8 @@ __device__ __forceinline__ void po_frame_env16(const KPoParams &P, const KPoStat
         const float w = qw * inv, x = qx * inv, y = qy * inv, z = qz * inv;
         const float ya = l16 == 0 ? 2.f * (w * x + y * z) : (l16 == 1 ? 2.f * (w * z + x * y) : hy);
         const float xa = l16 == 0 ? 1.f - 2.f * (x * x + y * y) : (l16 == 1 ? 1.f - 2.f * (y * y + z * z) : hx);
-        const float ang = atan2f(ya, xa);
-        const float pit = asinf(fminf(fmaxf(2.f * (w * y - z * x), -1.f), 1.f));
+        const float ang = po_atan2(ya, xa);
+        const float pit = po_asin(fminf(fmaxf(2.f * (w * y - z * x), -1.f), 1.f));
         if (l16 == 0) fr[6] = ang;                                     // roll
         if (l16 == 1) fr[8] = ang;                                     // yaw
         if (l16 == 2) { fr[25] = ang; rf[25] = ang; }                  // heading angle of the command, control_inputs.py:69-73

@@ -235,3 +235,40 @@ def test_po_step_replays_from_a_hipgraph_like_eager():
     (v1, h1), (v2, h2) = a_env.commands(), b_env.commands()
     assert np.array_equal(v1, v2) and np.array_equal(h1, h2)
     a_env.close(); b_env.close()
+
+
+def test_po_atan2_form_is_accurate_to_3e7():
+    """qg_po_dev.h::po_atan2 / po_asin restated in NumPy float32 (same reduction, same Cephes polynomial, float32 arithmetic) against
+    numpy's float64 arctan2 / arcsin over the plane and the unit interval: the bound the kernel comment states."""
+    f = np.float32
+
+    def po_atan2(y, x):
+        y, x = y.astype(f), x.astype(f)
+        ax, ay = np.abs(x), np.abs(y)
+        mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            a = (mn * (f(1) / mx)).astype(f)
+        big = a > f(0.41421356237)
+        t = np.where(big, (a - f(1)) * (f(1) / (a + f(1))), a).astype(f)
+        z = (t * t).astype(f)
+        p = ((f(8.05374449538e-2) * z + f(-1.38776856032e-1)) * z + f(1.99777106478e-1)) * z + f(-3.33329491539e-1)
+        r = ((p * z).astype(f) * t + t + np.where(big, f(0.78539816339), f(0))).astype(f)
+        r = np.where(ay > ax, f(1.57079632679) - r, r)
+        r = np.where(x < 0, f(3.14159265359) - r, r)
+        r = np.where(mx == 0, f(0), r)
+        return np.copysign(r, y).astype(f)
+
+    rng = np.random.default_rng(0)
+    ang = rng.uniform(-np.pi, np.pi, 400000)
+    rad = 10.0 ** rng.uniform(-6, 6, ang.size)
+    y, x = rad * np.sin(ang), rad * np.cos(ang)
+    err = np.abs(po_atan2(y, x).astype(np.float64) - np.arctan2(y.astype(f).astype(np.float64), x.astype(f).astype(np.float64)))
+    err = np.minimum(err, 2 * np.pi - err)                  # the branch cut at +-pi
+    assert err.max() < 3e-7, err.max()
+    for yy, xx in ((0.0, 1.0), (0.0, -1.0), (1.0, 0.0), (-1.0, 0.0), (0.0, 0.0), (1.0, 1.0), (-1.0, -1.0)):
+        got = float(po_atan2(np.array([yy]), np.array([xx]))[0])
+        assert abs(got - np.arctan2(yy, xx)) < 3e-7, (yy, xx, got)
+    v = np.concatenate([rng.uniform(-1, 1, 200000), 1 - 10.0 ** rng.uniform(-7, -1, 50000), [-1.0, 1.0, 0.0]]).astype(f)
+    s = np.sqrt(np.maximum((f(1) - v) * (f(1) + v), f(0))).astype(f)
+    err = np.abs(po_atan2(v, s).astype(np.float64) - np.arcsin(v.astype(np.float64)))
+    assert err.max() < 5e-7, err.max()
