@@ -1108,6 +1108,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     const int lane = threadIdx.x & (QGK_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     float *tile = tile_all[wave];
+    QG_MARK(0);
     if constexpr (!BAKED) {
         const float *src = reinterpret_cast<const float *>(Mp);
         float *dst = reinterpret_cast<float *>(&smodel);
@@ -1211,9 +1212,11 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         // instruction-fetch lines -- the same loop, shifted by one dword through an unrelated edit of the prologue, measured
         // 18.57 instead of 18.36 us per launch at 4096 envs (same-box A/B of eight paddings).  Pinning the loop to a 64-byte
         // boundary makes its layout independent of what precedes it.
+        QG_MARK(1);                                  // state in registers, prologue stores issued
         asm volatile(".p2align 6");
 #pragma unroll 1
         for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
+        QG_MARK(2);                                  // physics done
         if (!lag) {   // un-lagged sensors (task.sensor_lag = 0): one extra forward pass on a scratch copy of the state
             BaseState B2 = B;
             LegState L2 = L;
@@ -1297,6 +1300,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             }
         }
     }
+    QG_MARK(3);                                      // obs tile written out
     const bool lead = live && k_e == 0;
     if (lead && !P.packed) {
         if constexpr (!WALK) P.reward[env_e] = reward;
@@ -1322,6 +1326,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             walk_stv<3>(WK.S.prev_ctrl + (size_t)env_e * 12 + 3 * k_e, aclip);                       // previous_ctrl moves on (:260-262)
         }
         sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
+        QG_MARK(4);                                  // channel terms + sums
         if (lead) walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
     }
     if (lead && P.comps) {
