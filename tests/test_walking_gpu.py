@@ -265,3 +265,42 @@ def test_fused_and_three_launch_walking_agree_on_a_modified_robot(fused_mapping)
     f1, a1, id1 = fused.estimates(); f2, a2, id2 = three.estimates()
     assert np.allclose(f1, f2, atol=1e-5) and np.allclose(a1, a2, atol=1e-5) and np.allclose(id1, id2, atol=1e-5)
     fused.close(); three.close()
+
+
+def test_estimator_is_bit_identical_across_mappings_at_scale():
+    """The estimator is fed with data.ctrl (the clipped actions), not with anything the physics computes, so its outputs must not
+    depend on the work mapping AT ALL: the six-channels-per-lane form with 12-byte accesses inside the two-legs-per-lane kernel
+    (AUTO at 20 000 envs), the three-channel form of the one-leg-per-lane kernel and the one-channel stand-alone kernel (LANE: three
+    launches) give bit-identical frequency / amplitude estimates over 270 steps -- past the wrap of the 250-sample window, i.e.
+    through block entries with and without old samples behind the write index, the partial last block and the other-blocks cache."""
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    n = 20000
+    envs = {}
+    for name, mapping in (("pair", None), ("quad", _abi.MAP_QUAD), ("lane", _abi.MAP_LANE)):
+        e = WalkingQuadrupedVecEnv(n, frame_skip=4, max_time=100.0, seed=1)
+        if mapping is not None:
+            e._sim.set_mapping(mapping)
+        e.reset()
+        envs[name] = e
+    assert envs["pair"]._sim.mapping == _abi.MAP_PAIR
+    import torch
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(21)
+    obs = torch.empty((n, 33), device=dev); rew = torch.empty(n, device=dev); done = torch.empty(n, device=dev, dtype=torch.uint8)
+    t = torch.arange(12, device=dev, dtype=torch.float32)
+    for k in range(270):
+        # smooth signals of different frequency per channel plus noise, beyond the clip now and then
+        a = 0.9 * torch.sin(0.05 * k * (1.0 + t) + t)[None, :] + 0.3 * (torch.rand((n, 12), generator=gen, device=dev) - 0.5)
+        a = a.contiguous()
+        for e in envs.values():
+            e.step_tensor(a, obs, rew, done)
+        if k in (5, 17, 249, 250, 251, 269):
+            torch.cuda.synchronize()
+            ref = envs["lane"].estimates()
+            for name in ("pair", "quad"):
+                got = envs[name].estimates()
+                assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), (k, name)
+    f_est, a_est, _ = envs["lane"].estimates()
+    assert np.isfinite(f_est).all() and (a_est > 0.5).all() and (f_est > 0).any()
+    for e in envs.values():
+        e.close()
