@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("mapping", ["auto", "quad", "pair", "lane"])
 @pytest.mark.parametrize("frame_skip", [4, 20])
 def test_walking_rewards_match_oracle(frame_skip, mapping):
-    """`auto` (= one link per lane at this size) and `quad` (one leg per lane) run the whole walking env-step as ONE launch (task
-    layer fused into the step kernel); `pair` / `lane` keep the three launches estimator -> physics -> reward.  All go through the
-    same device functions."""
+    """`auto` (= one link per lane at this size), `quad` (one leg per lane) and `pair` (two legs per lane) run the whole walking
+    env-step as ONE launch (task layer fused into the step kernel); `lane` keeps the three launches estimator -> physics -> reward.
+    All go through the same device functions."""
     from quadruped_gym_amd.envs.walking import REWARD_KEYS, WalkingQuadrupedVecEnv
     n = 70
     settle = 0.05
@@ -304,3 +304,51 @@ def test_estimator_is_bit_identical_across_mappings_at_scale():
     assert np.isfinite(f_est).all() and (a_est > 0.5).all() and (f_est > 0).any()
     for e in envs.values():
         e.close()
+
+
+def test_walking_at_config3_size_matches_oracle_on_a_sample():
+    """The walking env-step at BASELINE config 3's size (32 768 envs: the two-legs-per-lane kernel with the task layer fused in, 1 024
+    waves in four-wave workgroups) against the NumPy oracle on a strided sample of 256 envs, 290 steps (past the wrap of the
+    250-sample estimator window); the oracle is fed the sampled envs' own observations, as in the small-batch test above."""
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    n, m, fs = 32768, 256, 4
+    pick = np.arange(m) * (n // m) + 7
+    env = WalkingQuadrupedVecEnv(n, frame_skip=fs, max_time=1000.0)
+    assert env._sim.mapping == _abi.MAP_PAIR
+    dt = 0.002 * fs
+    o = W.WalkingOracle(m, dt, settling_time=0.0)
+    rng = np.random.default_rng(8)
+    sp, al, th = rng.uniform(0.1, 0.5, n), rng.uniform(-np.pi, np.pi, n), rng.uniform(-np.pi, np.pi, n)
+    vel = np.stack([sp * np.cos(al), sp * np.sin(al)], 1).astype(np.float32)
+    head = np.stack([np.cos(th), np.sin(th)], 1).astype(np.float32)
+    for j, i in enumerate(pick):
+        o.controls.set_orientation(j, th[i])
+        o.controls.set_velocity_speed_alpha(j, sp[i], al[i])
+    env.set_commands(vel, head)
+    env.reset()
+    o.reset()
+    t = 0.0
+    data_ctrl = np.tile([0, 0, -0.5] * 4, (m, 1)).astype(np.float64)
+    ph = rng.uniform(0, 2 * np.pi, (n, 12)).astype(np.float32); fr = rng.uniform(0.5, 4.0, (n, 12)).astype(np.float32)
+    am = rng.uniform(0.1, 1.2, (n, 12)).astype(np.float32)
+    worst = 0.0
+    for k in range(290):
+        a = (am * np.sin(2 * np.pi * fr * (k * dt) + ph)).astype(np.float32)
+        obs, rew, dones, infos = env.step(a)
+        assert not dones[pick].any()
+        act = o.pre_step(np.full(m, t), data_ctrl, a[pick].astype(np.float64))
+        ctrl = np.clip(act, -1, 1)
+        tot, comps, flip = o.post_step(obs[pick].astype(np.float64), ctrl)
+        got = env.last_components[pick].astype(np.float64)
+        ok = np.isfinite(comps[:, :10]) & np.isfinite(got[:, :10])
+        assert np.allclose(got[:, :10][ok], comps[:, :10][ok], rtol=2e-4, atol=2e-4), (k, np.abs(got[:, :10] - comps[:, :10])[ok].max())
+        assert np.allclose(got[:, 10], comps[:, 10], rtol=1e-3, atol=2e-2 / dt * 1e-3 + 1e-3), k
+        worst = max(worst, float(np.abs(got[:, :10] - comps[:, :10])[ok].max()))
+        data_ctrl = ctrl
+        for _ in range(fs):
+            t += 0.002
+    f, amp, ideal = env.estimates()
+    assert np.allclose(f[pick], o.f_est, rtol=1e-4, atol=1e-4) and np.allclose(amp[pick], o.a_est, rtol=1e-4, atol=1e-5)
+    assert np.isfinite(env._sim.get_state()[0]).all()
+    print(f"largest component difference on the sample: {worst:.2e}")
+    env.close()
