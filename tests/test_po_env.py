@@ -140,14 +140,15 @@ def test_po_step_tensor_equals_host_step():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window,modified", [(1, False), (4, False), (10, False), (12, False), (64, False), (10, True)])
-def test_po_fused_launch_equals_separate_launches(window, modified, monkeypatch):
+@pytest.mark.parametrize("window,modified,n", [(1, False, 40), (4, False, 40), (10, False, 40), (12, False, 40), (64, False, 40), (10, True, 40),
+                                                (10, False, 4096)])
+def test_po_fused_launch_equals_separate_launches(window, modified, n, monkeypatch):
     """Up to 4096 envs the whole partially observable step is ONE launch (physics + walking task layer + observation pack in
     qg_step_kernel_link<WALK, PO>); QG_PO_UNFUSED=1 at construction keeps the observation pack a launch of its own.  Same
     arithmetic, same order: physics, rewards, terminations and re-drawn commands must agree to the bit; the frames to the last bits
     of the filter's Euler angles (the two kernels contract the same expressions into different FMAs)."""
     from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
-    n, fs = 40, 4                                                  # 2.5 workgroups of the fused kernel
+    fs = 4                                                         # n = 40: 2.5 workgroups of the fused kernel; 4096: the full grid
     kw = dict(obs_window=window, settling_time=0.05, frame_skip=fs, max_time=0.12, random_init=True, random_controls=True,
               device_commands=True, seed=11, reset_options={"min_speed": 0.1, "max_speed": 0.4})
     import quadruped_gym_amd.envs.walking as W
