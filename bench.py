@@ -523,36 +523,44 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
-        def all_ok(flag):
-            t = torch.tensor([flag], device=dev, dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            torch.cuda.synchronize(dev)
-            return int(t.item()) == 1
-        ok, note, dt_g = 1, None, float("inf")
-        try:                                             # phase 1: capture (no replay yet)
-            if fault == "raise":
+        from quadruped_gym_amd.dist import make_all_ok, negotiate_graph_replay
+
+        def capture():
+            if fault == "raise" or fault == f"raise@{rank}":
                 raise RuntimeError("injected capture failure (QG_BENCH_GRAPH_FAULT=raise)")
             if fault == "stall":
                 time.sleep(3600)
             build_graph(G)
-        except Exception as e:                           # capture refused on this rank
-            ok, note = 0, f"{type(e).__name__}: {e}"[:300]
-        # every rank learns whether EVERY rank holds a graph before any of them replays one: a rank that failed to capture
-        # would otherwise sit in this all_reduce while its peers issue the captured gathers (mismatched collectives)
-        captured = all_ok(ok)
-        if not captured:
+
+        def local_fence():                               # no collective in here (the protocol's all-reduces are the barriers)
+            if gatherer is not None:
+                gatherer.drain()
+            torch.cuda.synchronize(dev)
+
+        def warm_replay():
+            if fault == f"replay@{rank}":
+                raise RuntimeError("injected replay failure (QG_BENCH_GRAPH_FAULT=replay@rank)")
+            run(0, G)                                    # one replay as warm-up
+            local_fence()
+
+        def timed_replay():
+            torch.cuda.set_stream(state["side"])
+            run(args.warmup, args.steps)
+            local_fence()
+
+        def drop_graph():
             state["graph"] = None
             torch.cuda.set_stream(compute)
-        else:
-            try:                                         # phase 2: replay
-                run(0, G)                                # one replay as warm-up
-                fence()
-                dt_g, _ = timed(args.steps)
-            except Exception as e:
-                ok, note = 0, f"{type(e).__name__}: {e}"[:300]
-                state["graph"] = None
-                torch.cuda.set_stream(compute)
-        agreed = all_ok(ok) if captured else False
+
+        def reduce_max(x):
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        # capture -> does EVERY rank hold a graph? -> one replay -> did every rank get through it? -> K steps -> closing all-reduce
+        # -> MAX over ranks: quadruped_gym_amd.dist.negotiate_graph_replay (world-2 gloo tests with a rank that fails to capture /
+        # to replay: tests/test_dist_gloo.py)
+        att = negotiate_graph_replay(make_all_ok(None, dev), reduce_max, capture, warm_replay, timed_replay, drop_graph)
+        ok, note, dt_g, agreed = att.ok, att.note, att.seconds, att.agreed
         watchdog.cancel()
         plausible = ok == 1 and dt_g / args.steps * 1e3 >= 0.9 * kernel_ms     # a step cannot take less than its own kernel
         tried = {"eager (one torch.distributed gather per step)": round(dt / args.steps * 1e6, 2)}      # us per step of every loop that completed

@@ -6,17 +6,20 @@
 // inertia about the FRAME origin, bias force, ground contact: two thirds of the leg pass -- runs once instead of three times per
 // wave, and 4096 envs fill all 1024 SIMDs.  Lane r = 3 of each leg is a spare: it carries the leg's quarter of the FRAME's
 // contact sample points.
-//   * kinematic chain: lane r executes chain steps 0..r (execution-masked), so after the chain every lane holds its own link's
-//     frame, velocity and bias acceleration; the chain's constants are literals (the quarter-turn frame makes every leg "leg 0");
+//   * a lane r < 3 also owns HINGE r of its leg (state, servo filter, integration; round 3 -- every lane of the leg used to carry all
+//     three); the sines / cosines of the leg's three hinge rotations are broadcast over the leg's lanes at the head of a substep;
+//   * kinematic chain: the three FRAMES are built in every lane (literal mounts: the quarter-turn frame makes every leg "leg 0"), the
+//     lane picks its own link's; velocity and bias acceleration are PREFIX sums over the leg's lanes of one term per lane
+//     (qd_r S_r, qd_r v_r x S_r; two fused DPP adds per value);
 //   * link body: the same code in every lane on per-lane constants (mass, inertia, eight contact points of link r: held in
 //     registers, loaded once per launch);
 //   * backward pass inside the leg's four lanes with DPP quad_perm: composite inertia / force = suffix sums over r (two DPP adds per
 //     value), lane r forms column r of the leg's 3x3 joint block and its joint's servo / limit / damping terms, the nine numbers of
 //     the block and right-hand side are broadcast and every lane factors the same 3x3; the Schur complement is the sum of the rank-1
 //     terms z_r z_r^T / d_r, z = L^-1 F, one per lane;
-//   * the 33 base-block numbers (+ 4 of the FRAME contact) are summed over the env's 16 lanes with a symmetric DPP butterfly
-//     (quad_perm, quad_perm, row_half_mirror, row_mirror: every lane gets the bit-identical sum); base prelude, 6x6 solve and base
-//     integration run redundantly in the 16 lanes; the three hinges of a leg are integrated redundantly in its four lanes.
+//   * the 33 base-block numbers (+ 4 of the FRAME contact, whose twelve sample points are shared out one per link lane) are summed
+//     over the env's 16 lanes with a symmetric DPP butterfly (quad_perm, quad_perm, row_half_mirror, row_mirror: every lane gets the
+//     bit-identical sum); base prelude, 6x6 solve and base integration run redundantly in the 16 lanes.
 // Lagged sensors only (the reference's), at most one wave per SIMD: the launcher uses it for n <= 4096.  Two variants as for the
 // one-leg-per-lane kernel: the compiled-in robot with literal constants, any other robot with the model tables staged in LDS.
 #define QGK_LINK_ENVS 4     // envs per wave
@@ -26,7 +29,11 @@ template <int CTRL> DEV float dpp_any(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 // sum over the 16 lanes of an env (one DPP row); symmetric at every level, so all 16 lanes hold identical bits
+// (fp contract off inside these helpers: with the default "fast" contraction the backend folds a multiply that feeds `x` into the
+// first add -- fma(a, b, dpp(a * b)) -- which keeps the product alive twice and leaves the DPP move unfused: mul + mov_dpp + fma
+// instead of mul + add_dpp)
 DEV float env_sum(float x) {
+#pragma clang fp contract(off)
     x += dpp_any<0xB1>(x);    // quad_perm [1,0,3,2]
     x += dpp_any<0x4E>(x);    // quad_perm [2,3,0,1]
     x += dpp_any<0x141>(x);   // row_half_mirror
@@ -36,6 +43,7 @@ DEV float env_sum(float x) {
 DEV V3 env_sum(V3 a) { return v3(env_sum(a.x), env_sum(a.y), env_sum(a.z)); }
 // suffix sum over the links of a leg, lanes r = 0,1,2 (lane 3 must hold 0): lane r gets x_r + x_{r+1} + ... + x_2
 DEV float leg_suffix(float x) {
+#pragma clang fp contract(off)
     x += dpp_any<0xF9>(x);    // quad_perm [1,2,3,3]
     x += dpp_any<0xFE>(x);    // quad_perm [2,3,3,3] of the partial sums: lane 0 adds (x2 + x3), lane 1 adds x3 = 0
     return x;
@@ -44,26 +52,50 @@ DEV float leg_bcast0(float x) { return dpp_any<0x00>(x); }
 DEV float leg_bcast1(float x) { return dpp_any<0x55>(x); }
 DEV float leg_bcast2(float x) { return dpp_any<0xAA>(x); }
 
+// inclusive prefix sum over the links of a leg, lanes r = 0,1,2 (lane 3 must hold 0): lane r gets x_0 + ... + x_r
+DEV float leg_prefix(float x) {
+#pragma clang fp contract(off)
+    x += dpp_any<0xD3>(x);    // quad_perm [3,0,1,3]: the link below (lane 0 reads the spare lane's zero, which stays zero)
+    x += dpp_any<0x4F>(x);    // quad_perm [3,3,0,1] of the partial sums: lane 2 adds x_0
+    return x;
+}
+DEV V3 leg_prefix(V3 a) { return v3(leg_prefix(a.x), leg_prefix(a.y), leg_prefix(a.z)); }
+
 // what link r needs as per-lane data (registers)
 struct LinkRegs {
     float mass, ipos[3], inertia[6], cp[QGK_CP_LINK][3];
-    float lo, hi, damping, armature, kp, kv, gear, force_lo, force_hi;
+    float lo, hi, damping, armature, kp, kv, gear, force_lo, force_hi, act_decay;
+    float cpF[3];       // this lane's sample point of the FRAME (one of its twelve; the spare lanes carry none)
+    float ml;           // 1 in the lanes that own a link, 0 in the spare lane
 };
-struct LegJoints { float q[3], qd[3], act[3], u[3], sc[6]; };
+// this lane's hinge: lane r < 3 of leg k owns hinge 3k + r; the spare lane shadows hinge 3k + 2 (its copy is never stored)
+struct HingeLane { float q, qd, act, u, sn, cs; };
 
 DEV float sel3(int r, float a, float b, float c) { return r == 0 ? a : (r == 1 ? b : c); }
+DEV V3 sel3(int r, V3 a, V3 b, V3 c) { return v3(sel3(r, a.x, b.x, c.x), sel3(r, a.y, b.y, c.y), sel3(r, a.z, b.z, c.z)); }
 
 // BAKED: the compiled-in robot, whose legs are quarter-turn copies of one another: the chain's constants are literals and the lane
 // works in its leg's quarter-turn frame (cm, sm).  Otherwise `C` is the model staged in LDS and the chain reads leg kleg's own links.
+//
+// Round 3 ("instruction diet", 1 517 -> see DESIGN section 4 for the count): every lane used to carry the leg's three hinges and to run
+// the whole kinematic chain -- frames, velocities, bias accelerations of all three links -- committing what it met on the way under
+// its execution mask.  Now
+//   * a lane owns ONE hinge (state, servo filter, integration: once instead of three times per lane); the sines / cosines of the
+//     leg's three hinge rotations are broadcast over the leg's lanes at the head of the substep (six DPP moves);
+//   * only the frames of the chain are built in sequence (with literal mounts that is ~50 instructions for the three links); the
+//     lane then picks its own link's frame (selects), and
+//   * velocity and bias acceleration are PREFIX SUMS over the leg's lanes of one term per lane, qd_r S_r and qd_r (v_r x S_r):
+//     two fused DPP adds per value instead of every lane walking the chain;
+//   * the FRAME's twelve contact sample points are shared out one per link lane (the spare lane alone used to evaluate three).
 template <bool BAKED>
-DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg, bool lead_env, BaseState &B, LegJoints &J, const LinkRegs &K,
+DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env, BaseState &B, HingeLane &J, const LinkRegs &K,
                       bool want_sensors, float *__restrict__ row, int kleg, float &zaxis_z) {
     const float h = C.h;
     const BaseCtx bc = base_prelude(C, B);
     const V3 nb = bc.n;
     if (want_sensors) {              // the step's sensordata describes the state at the start of its last substep
         zaxis_z = bc.cz.z;
-        if (lead_leg) { row[3 * kleg + 0] = J.q[0]; row[3 * kleg + 1] = J.q[1]; row[3 * kleg + 2] = J.q[2]; }
+        if (r < 3) row[3 * kleg + r] = J.q;
         if (lead_env) {
             row[15] = B.wb.x; row[16] = B.wb.y; row[17] = B.wb.z;
             row[18] = B.pw.x; row[19] = B.pw.y; row[20] = B.pw.z;
@@ -73,32 +105,48 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
             row[30] = bc.vb.x; row[31] = bc.vb.y; row[32] = bc.vb.z;
         }
     }
-    const int rr = r < 2 ? r : 2;                    // the spare lane shadows link 2 through the chain
-    // ---- kinematic chain: lane r runs steps 0..r --------------------------------------------------------------------------
-    Fr Ep = {v3(BAKED ? cm : 1.f, BAKED ? sm : 0.f, 0.f), v3(BAKED ? -sm : 0.f, BAKED ? cm : 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-    V3 pp = v3(0.f, 0.f, 0.f);
-    SV vp = bc.V0, ap = bc.A0;
-    // every lane computes every step (S[i] of a descendant is never read by an ancestor's lane); only the carry -- frame, origin,
-    // velocity, bias acceleration: what the lane keeps as ITS link's -- is committed under the lane's mask
+    const int rr = r < 2 ? r : 2;                    // the spare lane shadows link 2
+    // ---- kinematic chain: the three frames in every lane of the leg ----------------------------------------------------------
+    const float snj[3] = {leg_bcast0(J.sn), leg_bcast1(J.sn), leg_bcast2(J.sn)};
+    const float csj[3] = {leg_bcast0(J.cs), leg_bcast1(J.cs), leg_bcast2(J.cs)};
+    Fr E[3];
+    V3 p[3];
     SV S[3];
+    {
+        Fr Ep = {v3(BAKED ? cm : 1.f, BAKED ? sm : 0.f, 0.f), v3(BAKED ? -sm : 0.f, BAKED ? cm : 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+        V3 pp = v3(0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const KLink &L = link_of<BAKED>(C, kleg, i);
-        const float sn = J.sc[2 * i], cs = J.sc[2 * i + 1];
-        V3 p = pp + rot(Ep, ld3(L.pos));
-        V3 tx = fma3(L.Q[0], Ep.ex, fma3(L.Q[3], Ep.ey, L.Q[6] * Ep.ez));
-        V3 ty = fma3(L.Q[1], Ep.ex, fma3(L.Q[4], Ep.ey, L.Q[7] * Ep.ez));
-        V3 tz = fma3(L.Q[2], Ep.ex, fma3(L.Q[5], Ep.ey, L.Q[8] * Ep.ez));
-        Fr E = {fma3(cs, tx, sn * ty), fma3(cs, ty, (-sn) * tx), tz};
-        S[i].a = E.ez;
-        S[i].l = cross(p, E.ez);
-        SV v = {fma3(J.qd[i], S[i].a, vp.a), fma3(J.qd[i], S[i].l, vp.l)};
-        SV a;
-        a.a = fma3(J.qd[i], cross(v.a, S[i].a), ap.a);
-        a.l = fma3(J.qd[i], cross(v.a, S[i].l) + cross(v.l, S[i].a), ap.l);
-        if (i <= rr) { Ep = E; pp = p; vp = v; ap = a; }
+        for (int i = 0; i < 3; ++i) {
+            const KLink &L = link_of<BAKED>(C, kleg, i);
+            const float sn = snj[i], cs = csj[i];
+            p[i] = pp + rot(Ep, ld3(L.pos));
+            V3 tx = fma3(L.Q[0], Ep.ex, fma3(L.Q[3], Ep.ey, L.Q[6] * Ep.ez));
+            V3 ty = fma3(L.Q[1], Ep.ex, fma3(L.Q[4], Ep.ey, L.Q[7] * Ep.ez));
+            V3 tz = fma3(L.Q[2], Ep.ex, fma3(L.Q[5], Ep.ey, L.Q[8] * Ep.ez));
+            E[i].ex = fma3(cs, tx, sn * ty);
+            E[i].ey = fma3(cs, ty, (-sn) * tx);
+            E[i].ez = tz;
+            S[i].a = E[i].ez;
+            S[i].l = cross(p[i], E[i].ez);
+            Ep = E[i]; pp = p[i];
+        }
     }
+    // this lane's link: frame, origin, joint axis
+    const Fr Ep = {sel3(rr, E[0].ex, E[1].ex, E[2].ex), sel3(rr, E[0].ey, E[1].ey, E[2].ey), sel3(rr, E[0].ez, E[1].ez, E[2].ez)};
+    const V3 pp = sel3(rr, p[0], p[1], p[2]);
     const SV So = {Ep.ez, cross(pp, Ep.ez)};
+    // velocity and bias acceleration of the link: prefix sums over the leg's lanes (the spare lane contributes nothing)
+    SV vp, ap;
+    {
+        const float qdm = K.ml * J.qd;
+        vp.a = leg_prefix(qdm * So.a) + bc.V0.a;
+        vp.l = leg_prefix(qdm * So.l) + bc.V0.l;
+        // a = a_parent + (v x S) qd, v the link's own velocity
+        const V3 ca = qdm * cross(vp.a, So.a);
+        const V3 cl = qdm * (cross(vp.a, So.l) + cross(vp.l, So.a));
+        ap.a = leg_prefix(ca) + bc.A0.a;
+        ap.l = leg_prefix(cl) + bc.A0.l;
+    }
     // ---- this lane's link: rigid inertia about the FRAME origin (FRAME axes), bias force, ground contact -------------------------
     Rigid Bi;
     Bi.m = K.mass;
@@ -132,7 +180,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
         const float zb = C.contact_margin - zo;
 #pragma unroll
         for (int i = 0; i < QGK_CP_LINK; ++i) contact_point(v3(K.cp[i][0], K.cp[i][1], K.cp[i][2]), nl, zb, wsum, s);
-        if (r == 3) wsum = 0.f;                     // the spare lane is no link (its mass and inertia are zero as well)
+        wsum *= K.ml;                               // the spare lane is no link (its mass and inertia are zero as well)
         SV fe;
         ContactDampT<float> cd;
         contact_eval(wsum, s, Ep, pp, nb, vp, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, cd);
@@ -140,23 +188,11 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
         f.l = f.l - fe.l;
         add_contact_damping(A, cd.mc, cd.w, cd.P, nb);
     }
-    // FRAME contact: the spare lane of leg k evaluates that leg's quarter turn of the three base sample points
+    // FRAME contact: every link lane evaluates one of the FRAME's twelve sample points
     float wsumF = 0.f;
     V3 sF = v3(0.f, 0.f, 0.f);
-    {
-        const float zbF = C.contact_margin - B.pw.z;
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            if constexpr (BAKED) {
-                V3 r0 = ld3(C.cp0[4 * o]);
-                contact_point(v3(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, r0.z), nb, zbF, wsumF, sF);
-            } else {
-                contact_point(ld3(C.cp0[3 * kleg + o]), nb, zbF, wsumF, sF);   // any partition of the 12 points over the 4 spare lanes
-            }
-        }
-        const float mF = r == 3 ? 1.f : 0.f;
-        wsumF *= mF; sF = mF * sF;
-    }
+    contact_point(v3(K.cpF[0], K.cpF[1], K.cpF[2]), nb, C.contact_margin - B.pw.z, wsumF, sF);
+    wsumF *= K.ml; sF = K.ml * sF;
     // ---- composite inertia and force of the subtree rooted at this link: suffix sums over the leg's lanes ----------------------------
     Sym6 Ic;
     SV fc;
@@ -175,7 +211,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
     const float tb = dot(So, fc);
     float Hd_o, b_o;
     {
-        const float q = sel3(rr, J.q[0], J.q[1], J.q[2]), qd = sel3(rr, J.qd[0], J.qd[1], J.qd[2]), act = sel3(rr, J.act[0], J.act[1], J.act[2]);
+        const float q = J.q, qd = J.qd, act = J.act;
         // position servo (quadruped.xml:10-37): force from the PRE-update activation
         float force = K.kp * (act - K.gear * q) - (K.kv * K.gear) * qd;
         const bool clamped = force <= K.force_lo || force >= K.force_hi;
@@ -223,23 +259,23 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
 #pragma unroll
         for (int i = 0; i < 6; ++i) z[i] = fmaf(-c1, zb1[i], z[i]);
     }
-    // ---- this lane's share of the base block: (r == 0: the leg's composite inertia and force) - z z^T / d_r, F u = sum_r z_r y_r / d_r ----
+    // ---- this lane's share of the base block: its own link's inertia and force (summed over the env's lanes they are the legs' composite
+    // inertias and forces) minus z z^T / d_r;  F u = sum_r z_r y_r / d_r ----
     const float idr = sel3(rr, id0, id1, id2), yr = sel3(rr, y0, y1, y2);
     float w[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = idr * z[i];
-    const float m0 = r == 0 ? 1.f : 0.f;
     Sym6 Cn;
-    Cn.AA.xx = fmaf(m0, Ic.AA.xx, -(w[0] * z[0])); Cn.AA.yy = fmaf(m0, Ic.AA.yy, -(w[1] * z[1])); Cn.AA.zz = fmaf(m0, Ic.AA.zz, -(w[2] * z[2]));
-    Cn.AA.xy = fmaf(m0, Ic.AA.xy, -(w[0] * z[1])); Cn.AA.xz = fmaf(m0, Ic.AA.xz, -(w[0] * z[2])); Cn.AA.yz = fmaf(m0, Ic.AA.yz, -(w[1] * z[2]));
-    Cn.AL.r0 = v3(fmaf(m0, Ic.AL.r0.x, -(w[0] * z[3])), fmaf(m0, Ic.AL.r0.y, -(w[0] * z[4])), fmaf(m0, Ic.AL.r0.z, -(w[0] * z[5])));
-    Cn.AL.r1 = v3(fmaf(m0, Ic.AL.r1.x, -(w[1] * z[3])), fmaf(m0, Ic.AL.r1.y, -(w[1] * z[4])), fmaf(m0, Ic.AL.r1.z, -(w[1] * z[5])));
-    Cn.AL.r2 = v3(fmaf(m0, Ic.AL.r2.x, -(w[2] * z[3])), fmaf(m0, Ic.AL.r2.y, -(w[2] * z[4])), fmaf(m0, Ic.AL.r2.z, -(w[2] * z[5])));
-    Cn.LL.xx = fmaf(m0, Ic.LL.xx, -(w[3] * z[3])); Cn.LL.yy = fmaf(m0, Ic.LL.yy, -(w[4] * z[4])); Cn.LL.zz = fmaf(m0, Ic.LL.zz, -(w[5] * z[5]));
-    Cn.LL.xy = fmaf(m0, Ic.LL.xy, -(w[3] * z[4])); Cn.LL.xz = fmaf(m0, Ic.LL.xz, -(w[3] * z[5])); Cn.LL.yz = fmaf(m0, Ic.LL.yz, -(w[4] * z[5]));
-    // right-hand side share: -(m0 * fc + z_r y_r / d_r)
-    SV rhn = {v3(fmaf(-m0, fc.a.x, -(yr * w[0])), fmaf(-m0, fc.a.y, -(yr * w[1])), fmaf(-m0, fc.a.z, -(yr * w[2]))),
-              v3(fmaf(-m0, fc.l.x, -(yr * w[3])), fmaf(-m0, fc.l.y, -(yr * w[4])), fmaf(-m0, fc.l.z, -(yr * w[5])))};
+    Cn.AA.xx = fmaf(-w[0], z[0], A.AA.xx); Cn.AA.yy = fmaf(-w[1], z[1], A.AA.yy); Cn.AA.zz = fmaf(-w[2], z[2], A.AA.zz);
+    Cn.AA.xy = fmaf(-w[0], z[1], A.AA.xy); Cn.AA.xz = fmaf(-w[0], z[2], A.AA.xz); Cn.AA.yz = fmaf(-w[1], z[2], A.AA.yz);
+    Cn.AL.r0 = v3(fmaf(-w[0], z[3], A.AL.r0.x), fmaf(-w[0], z[4], A.AL.r0.y), fmaf(-w[0], z[5], A.AL.r0.z));
+    Cn.AL.r1 = v3(fmaf(-w[1], z[3], A.AL.r1.x), fmaf(-w[1], z[4], A.AL.r1.y), fmaf(-w[1], z[5], A.AL.r1.z));
+    Cn.AL.r2 = v3(fmaf(-w[2], z[3], A.AL.r2.x), fmaf(-w[2], z[4], A.AL.r2.y), fmaf(-w[2], z[5], A.AL.r2.z));
+    Cn.LL.xx = fmaf(-w[3], z[3], A.LL.xx); Cn.LL.yy = fmaf(-w[4], z[4], A.LL.yy); Cn.LL.zz = fmaf(-w[5], z[5], A.LL.zz);
+    Cn.LL.xy = fmaf(-w[3], z[4], A.LL.xy); Cn.LL.xz = fmaf(-w[3], z[5], A.LL.xz); Cn.LL.yz = fmaf(-w[4], z[5], A.LL.yz);
+    // right-hand side share: -(f_own + z_r y_r / d_r)
+    SV rhn = {v3(fmaf(-yr, w[0], -f.a.x), fmaf(-yr, w[1], -f.a.y), fmaf(-yr, w[2], -f.a.z)),
+              v3(fmaf(-yr, w[3], -f.l.x), fmaf(-yr, w[4], -f.l.y), fmaf(-yr, w[5], -f.l.z))};
     // ---- base block: FRAME body + contact first (a wave-uniform branch), then the sums over the env's 16 lanes and the 6x6 solve, all
     // redundant in the 16 lanes.  The sums come after the branch so that each DPP move sits in one basic block with the add that
     // consumes it (the compiler fuses them into v_add_f32_dpp only then).
@@ -270,22 +306,18 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_leg,
     if (want_sensors && lead_env) {
         row[12] = acl.x - bc.gb.x; row[13] = acl.y - bc.gb.y; row[14] = acl.z - bc.gb.z;   // accelerometer
     }
-    // ---- hinge accelerations  qdd = H^-1 (b - F^T x)  with the factors every lane of the leg holds ---------------------------------------
+    // ---- hinge accelerations  qdd = H^-1 (b - F^T x)  with the factors every lane of the leg holds; the lane integrates ITS hinge ---------
     {
         const float g_o = fmaf(F.a.x, x6[0], fmaf(F.a.y, x6[1], fmaf(F.a.z, x6[2], fmaf(F.l.x, x6[3], fmaf(F.l.y, x6[4], F.l.z * x6[5])))));
         const float r0 = b0 - leg_bcast0(g_o), r1 = b1 - leg_bcast1(g_o), r2 = b2 - leg_bcast2(g_o);
         const float yy0 = r0, yy1 = fmaf(-l10, yy0, r1), yy2 = fmaf(-l21, yy1, fmaf(-l20, yy0, r2));
-        float qdd[3];
-        qdd[2] = yy2 * id2;
-        qdd[1] = fmaf(-l21, qdd[2], yy1 * id1);
-        qdd[0] = fmaf(-l20, qdd[2], fmaf(-l10, qdd[1], yy0 * id0));
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            J.qd[i] = fmaf(h, qdd[i], J.qd[i]);
-            J.q[i] = fmaf(h, J.qd[i], J.q[i]);
-            hinge_advance(h * J.qd[i], J.sc[2 * i], J.sc[2 * i + 1]);
-            J.act[i] = fmaf(J.u[i] - J.act[i], link_of<BAKED>(C, kleg, i).act_decay, J.act[i]);
-        }
+        const float qdd2 = yy2 * id2;
+        const float qdd1 = fmaf(-l21, qdd2, yy1 * id1);
+        const float qdd0 = fmaf(-l20, qdd2, fmaf(-l10, qdd1, yy0 * id0));
+        J.qd = fmaf(h, sel3(rr, qdd0, qdd1, qdd2), J.qd);
+        J.q = fmaf(h, J.qd, J.q);
+        hinge_advance(h * J.qd, J.sn, J.cs);
+        J.act = fmaf(J.u - J.act, K.act_decay, J.act);
     }
     base_integrate(bc, h, wdot, acl, B);
 }
@@ -333,7 +365,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     const int n = P.n;
     const bool live = env0 + el < n;
     const int env = live ? env0 + el : n - 1;       // tail lanes shadow the last env; their stores are masked
-    const bool lead_leg = r == 0, lead_env = (lane & 15) == 0;
+    const bool lead_env = (lane & 15) == 0;
     const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
     const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
 
@@ -356,6 +388,16 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         for (int i = 0; i < QGK_CP_LINK; ++i) { K.cp[i][0] = QG_SEL(cp[i][0]); K.cp[i][1] = QG_SEL(cp[i][1]); K.cp[i][2] = QG_SEL(cp[i][2]); }
         K.lo = QG_SEL(lo); K.hi = QG_SEL(hi); K.damping = QG_SEL(damping); K.armature = QG_SEL(armature); K.kp = QG_SEL(kp);
         K.kv = QG_SEL(kv); K.gear = QG_SEL(gear); K.force_lo = QG_SEL(force_lo); K.force_hi = QG_SEL(force_hi);
+        K.act_decay = QG_SEL(act_decay);
+        K.ml = ml;
+        // the lane's sample point of the FRAME: the compiled-in robot's twelve are three points and their quarter-turn copies (index
+        // 4 o + k = point o turned by leg k's quarter turn); any other robot: any partition of the twelve over the twelve link lanes
+        if constexpr (BAKED) {
+            const float fx = sel3(rk, C.cp0[0][0], C.cp0[4][0], C.cp0[8][0]), fy = sel3(rk, C.cp0[0][1], C.cp0[4][1], C.cp0[8][1]);
+            K.cpF[0] = cm * fx - sm * fy; K.cpF[1] = sm * fx + cm * fy; K.cpF[2] = sel3(rk, C.cp0[0][2], C.cp0[4][2], C.cp0[8][2]);
+        } else {
+            K.cpF[0] = C.cp0[3 * k + rk][0]; K.cpF[1] = C.cp0[3 * k + rk][1]; K.cpF[2] = C.cp0[3 * k + rk][2];
+        }
 #undef QG_SEL
     }
 
@@ -365,18 +407,20 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
     const int nstep0 = P.st.nstep[env];
-    LegJoints J;
-    float aclip[3];
+    // this lane's hinge (the spare lane shadows hinge 2 of its leg: same loads, nothing of it is ever stored)
+    const int rk = r < 3 ? r : 2;
+    const int jch = 3 * k + rk;                      // hinge = control channel of this lane
+    HingeLane J;
+    float aclip;
     // WALK: every load of the task layer goes out among the state loads, every store of its prologue part after the last of them
     // (see qg_step_kernel_quad)
     const bool wch = live && r < 3;                 // this lane owns control channel 3k + r
-    const int jch = 3 * k + (r < 3 ? r : 2);
     bool settle = false;
     int calls = 0;
     WalkEnvIn win = {};
     WalkChanTargets wtg = {0.f, 0.f, 0.f};
     const int tt[1] = {env * 12 + jch};               // task state: [n][12]
-    float xx[1] = {0.f}, wprev = 0.f, wf[1] = {0.f}, wa[1] = {0.f}, a_eff[3] = {0.f, 0.f, 0.f};
+    float xx[1] = {0.f}, wprev = 0.f, wf[1] = {0.f}, wa[1] = {0.f}, a_eff = 0.f;
     WalkEstIn<1> west;
     if constexpr (WALK) {
         settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
@@ -385,7 +429,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         if (r < 3) {
             xx[0] = P.st.ctrl[jch * n + env];         // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
             wprev = WK.S.prev_ctrl[tt[0]];            // previous_ctrl of the control cost (:260-262)
-            walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west);
+            walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west, live);
         }
         if (lead_env) {
             win = walk_env_load(WK.S, n, env);
@@ -394,55 +438,51 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     }
     PoEnvIn pin = {};
     if constexpr (PO) pin = po_env_load(PK.S, n, env);      // every lane of the env: the history copy below needs the ring position
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = 3 * k + i;
-        float a_in = P.actions[(size_t)env * 12 + j];
+    {
+        float a_in = P.actions[(size_t)env * 12 + jch];
         if constexpr (WALK) {
-            if (settle) a_in = WK.P.joint_centers[j];                // the joint centres while the robot settles
-            a_eff[i] = a_in;
+            if (settle) a_in = wtg.center;                          // the joint centres while the robot settles
+            a_eff = a_in;
         }
-        float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
-        aclip[i] = a;
-        J.u[i] = fminf(fmaxf(a, link_of<BAKED>(C, k, i).ctrl_lo), link_of<BAKED>(C, k, i).ctrl_hi);
-        J.q[i] = P.st.qpos[(7 + j) * n + env];
-        J.qd[i] = P.st.qvel[(6 + j) * n + env];
-        J.act[i] = P.st.act[j * n + env];
-        sincos_f(J.q[i] - link_of<BAKED>(C, k, i).ref, J.sc[2 * i], J.sc[2 * i + 1]);
+        aclip = fminf(fmaxf(a_in, -1.f), 1.f);       // quadruped.py:160
+        const KLink &Lj = link_of<BAKED>(C, k, rk);
+        const float clo = BAKED ? sel3(rk, C.link[0].ctrl_lo, C.link[1].ctrl_lo, C.link[2].ctrl_lo) : Lj.ctrl_lo;
+        const float chi = BAKED ? sel3(rk, C.link[0].ctrl_hi, C.link[1].ctrl_hi, C.link[2].ctrl_hi) : Lj.ctrl_hi;
+        const float ref = BAKED ? sel3(rk, C.link[0].ref, C.link[1].ref, C.link[2].ref) : Lj.ref;
+        J.u = fminf(fmaxf(aclip, clo), chi);
+        J.q = P.st.qpos[(7 + jch) * n + env];
+        J.qd = P.st.qvel[(6 + jch) * n + env];
+        J.act = P.st.act[jch * n + env];
+        sincos_f(J.q - ref, J.sn, J.cs);
     }
     if constexpr (WALK) {
         asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
-                     "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(J.q[0]), "v"(J.q[1]), "v"(J.q[2]), "v"(J.qd[0]), "v"(J.qd[1]), "v"(J.qd[2]),
-                     "v"(J.act[0]), "v"(J.act[1]), "v"(J.act[2]) : "memory");
+                     "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(J.q), "v"(J.qd), "v"(J.act) : "memory");
         if (wch) {
             walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
-            WK.S.eff_actions[(size_t)env * 12 + jch] = sel3(r, a_eff[0], a_eff[1], a_eff[2]);   // the action actually applied (the PO pack reads it)
+            WK.S.eff_actions[(size_t)env * 12 + jch] = a_eff;   // the action actually applied (the PO pack reads it)
         }
     }
     if constexpr (PO) {
         int slot = pin.head + 1;
         if (slot >= PK.P.window) slot = 0;
-        if (PK.P.window > 1) po_copy_history(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out);
+        if (PK.P.window > 1) po_copy_history(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live);
     }
 
     float *srow = tile + el * 35;
     float zaxis_z = 1.f;
     const int fs = Tk.frame_skip;
 #ifdef QG_PHASE_TIMES
-    asm volatile("" :: "v"(B.pw.x), "v"(B.qw), "v"(B.vw.x), "v"(B.wb.x), "v"(J.q[0]), "v"(J.q[1]), "v"(J.q[2]), "v"(J.qd[0]), "v"(J.qd[1]), "v"(J.qd[2]),
-                 "v"(J.act[0]), "v"(J.act[1]), "v"(J.act[2]), "v"(J.sc[0]), "v"(J.sc[2]), "v"(J.sc[4]));
+    asm volatile("" :: "v"(B.pw.x), "v"(B.qw), "v"(B.vw.x), "v"(B.wb.x), "v"(J.q), "v"(J.qd), "v"(J.act), "v"(J.sn), "v"(J.cs));
 #endif
     QG_MARK(1);                                      // state in registers, prologue stores issued
     asm volatile(".p2align 6");
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_leg, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
+    for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
     int nstep = nstep0 + fs;
     QG_MARK(2);                                      // physics done
 
-    float ssq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ssq = fmaf(aclip[i], aclip[i], ssq);
-    ssq = env_sum(lead_leg ? ssq : 0.f);
+    const float ssq = env_sum(r < 3 ? aclip * aclip : 0.f);
     float c_fwd = Tk.w_forward * B.vw.x;
     float c_ctl = Tk.w_ctrl * ssq;
     float c_alive = Tk.alive_bonus;
@@ -450,8 +490,8 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     bool done = nstep >= Tk.limit_substeps;
     if (Tk.use_fall) done = done || (B.pw.z < Tk.fall_height);
     {
-        float probe = J.q[0] + J.q[1] + J.q[2] + J.qd[0] + J.qd[1] + J.qd[2];
-        probe = env_sum(lead_leg ? probe : 0.f) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+        float probe = J.q + J.qd;
+        probe = env_sum(r < 3 ? probe : 0.f) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
         done = done || state_is_bad(probe);
     }
     const int od = Tk.obs_mode == 1 ? 21 : 33;
@@ -481,15 +521,12 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         P.st.nstep[env] = nstep;
         if (rst) P.st.episode[env] += 1;
     }
-    if (live && lead_leg) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int j = 3 * k + i;
-            P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + (BAKED ? i : j)] : J.q[i];
-            P.st.qvel[(6 + j) * n + env] = rst ? 0.f : J.qd[i];
-            P.st.act[j * n + env] = rst ? 0.f : J.act[i];
-            if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? Tk.default_ctrl[j] : aclip[i];
-        }
+    if (wch) {                                      // every link lane stores its own hinge
+        const float q0 = BAKED ? sel3(rk, C.qpos0[7], C.qpos0[8], C.qpos0[9]) : C.qpos0[7 + jch];
+        P.st.qpos[(7 + jch) * n + env] = rst ? q0 : J.q;
+        P.st.qvel[(6 + jch) * n + env] = rst ? 0.f : J.qd;
+        P.st.act[jch * n + env] = rst ? 0.f : J.act;
+        if (P.track_ctrl) P.st.ctrl[jch * n + env] = rst ? Tk.default_ctrl[jch] : aclip;
     }
     if (lead_env) {
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
@@ -517,9 +554,8 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     if constexpr (WALK) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
         if (wch) {
-            const float c_own = sel3(r, aclip[0], aclip[1], aclip[2]);
-            walk_channel_terms(WK.S, env, jch, wtg, c_own, wprev, wf[0], wa[0], sum);
-            WK.S.prev_ctrl[tt[0]] = c_own;
+            walk_channel_terms(WK.S, env, jch, wtg, aclip, wprev, wf[0], wa[0], sum);
+            WK.S.prev_ctrl[tt[0]] = aclip;
         }
         sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
         QG_MARK(4);                                  // channel terms + sums
@@ -537,10 +573,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         __shared__ float s_rst[QG_PO_ENVS][QG_PO_FRAME];     // the frame reset() would return (only for envs that finished)
         __shared__ int s_slot[QG_PO_ENVS], s_fin[QG_PO_ENVS];
         const int le = threadIdx.x >> 4;                     // = 4 * wave + el
-        if (live && lead_leg) {                              // data.ctrl of the frame: the env-clipped action this step applied
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s_new[le][11 + 3 * k + i] = aclip[i];
-        }
+        if (wch) s_new[le][11 + jch] = aclip;                // data.ctrl of the frame: the env-clipped action this step applied
         if (live) {
             // the heading of the command, which the env's lead lane holds, into lane 2 as well (it evaluates the angle)
             const float hx = __shfl(win.hx, lane & ~15), hy = __shfl(win.hy, lane & ~15);

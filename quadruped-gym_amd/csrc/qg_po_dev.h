@@ -243,10 +243,12 @@ __device__ __forceinline__ void po_emit_rows(const KPoParams &P, const KPoState 
 // ring -> out there, their loads in flight together with the state loads (a wave that is alone on its SIMD would otherwise sit
 // through their latency in the epilogue, behind the stores of the step).  `slot` = ring slot the NEW frame will take.  One trip of 16 loads + 16 stores per lane covers obs_window <= 10.
 __device__ __forceinline__ void po_copy_history(const KPoParams &P, const KPoState &S, size_t row, int slot, int l16,
-                                                float *__restrict__ out) {
+                                                float *__restrict__ out, bool live = true) {
     // the new row is the ring rotated: out[r] = ring[(r + 26 * (slot + 1)) mod (26 W)] for r < 26 (W - 1).  Lanes past the end
-    // repeat element 26 (W - 1) - 1 (same value to the same address: harmless), so that no load or store is predicated; the lanes
-    // of a wave's tail (no env of their own) shadow the last env and repeat ITS copy.
+    // repeat element 26 (W - 1) - 1 (same value to the same address: harmless), so that no load is predicated; the lanes of a
+    // wave's tail (no env of their own, `live` false) shadow the last env's loads and store nothing -- a whole env is live or not,
+    // so the predicate costs no divergence inside an env, and nothing then orders a shadow copy against the epilogue of the wave
+    // that owns the env.
     const int W = P.window, width = W * QG_PO_FRAME, hist = width - QG_PO_FRAME;
     const int off = (slot + 1 >= W ? 0 : slot + 1) * QG_PO_FRAME;
     const float *__restrict__ st = S.stack + row;
@@ -262,7 +264,7 @@ __device__ __forceinline__ void po_copy_history(const KPoParams &P, const KPoSta
             v[u] = st[src];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) o[rr[u]] = v[u];
+        for (int u = 0; u < 16; ++u) if (live) o[rr[u]] = v[u];
     }
 }
 // Phase 1 of the fused form: the 16 lanes of the env run it together.  The filter update is redundant in all of them (no lane has

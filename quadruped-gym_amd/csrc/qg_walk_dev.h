@@ -144,7 +144,8 @@ template <int NCH> struct WalkEstIn {
 // phase 1: every load of the update: call it among the caller's other loads.  (On the call that enters a new block -- every 16th --
 // it also reads the block's 16 old samples and the 2 x 16 summaries and STORES the suffix extrema: a rare, slower path.)
 template <int NCH>
-__device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], int calls, WalkEstIn<NCH> &in) {
+__device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], int calls, WalkEstIn<NCH> &in,
+                                                      bool live = true /* false: a tail lane shadowing the last env -- loads only, no stores */) {
     const int W = P.window;
     const int idx = calls % W;
     const size_t stride = (size_t)12 * n;
@@ -216,8 +217,10 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
                     sh[c] = fmaxf(sh[c], valid ? old[c][j] : QG_WALK_EMPTY_MAX);
                     sl[c] = fminf(sl[c], valid ? old[c][j] : QG_WALK_EMPTY_MIN);
                 }
-                walk_stv<NCH>(S.smax + (size_t)j * stride + t0, sh);
-                walk_stv<NCH>(S.smin + (size_t)j * stride + t0, sl);
+                if (live) {
+                    walk_stv<NCH>(S.smax + (size_t)j * stride + t0, sh);
+                    walk_stv<NCH>(S.smin + (size_t)j * stride + t0, sl);
+                }
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { in.sh[c] = sh[c]; in.sl[c] = sl[c]; }     // j = 1: what stands behind the sample this call writes

@@ -137,3 +137,81 @@ class ActionScatterer:
         self.work[b].wait()
         self.work[b] = None
         return self.local[b]
+
+
+class GraphAttempt:
+    """Outcome of ``negotiate_graph_replay`` on this rank (identical ``captured`` / ``agreed`` on every rank)."""
+
+    def __init__(self):
+        self.captured = False     # every rank holds a captured graph
+        self.agreed = False       # every rank replayed it and finished the timed run
+        self.ok = 1               # this rank's own view: 0 as soon as anything raised here
+        self.note = None          # what raised here, if anything
+        self.seconds = float("inf")   # the timed run, MAX over ranks (only meaningful when ``agreed``)
+
+
+def make_all_ok(group=None, device=None):
+    """``all_ok(flag) -> bool``: all-reduce MIN of a 0/1 flag over ``group``; on a GPU the call returns after the device has
+    finished (so it doubles as barrier + synchronise)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+
+    def all_ok(flag):
+        t = torch.tensor([int(flag)], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return int(t.item()) == 1
+    return all_ok
+
+
+def negotiate_graph_replay(all_ok, reduce_max, capture, warm_replay, timed_replay, drop_graph, clock=None):
+    """The agreement protocol of ``bench.py --exchange auto``: try the K timed steps once more as hipGraph replays WITHOUT ever
+    leaving two ranks inside different collectives.
+
+    Every rank calls this with the same arguments; every collective in here is reached by every rank whatever happened locally:
+
+    1. ``capture()`` (local, may raise)                        -> ``all_ok``: does EVERY rank hold a graph?   no -> drop, done
+    2. ``warm_replay()`` (local work + local fence, may raise) -> ``all_ok``: did every rank get through one replay?  no -> drop, done
+       (this all-reduce is the opening barrier + synchronise of the timed region)
+    3. ``timed_replay()`` (exactly K steps + LOCAL fence, may raise) -> ``all_ok`` (the closing barrier) -> ``reduce_max(seconds)``
+
+    ``drop_graph()`` puts this rank back on the eager path (no collective in it).  A rank whose callable raises never skips a
+    collective, it only votes 0.  What the protocol cannot repair is a collective INSIDE a replayed graph that a failed peer never
+    joins: that is a stalled GPU, which the caller's watchdog reports with a non-zero exit status.  Returns a ``GraphAttempt``.
+    """
+    import time
+    clock = clock or time.perf_counter
+    out = GraphAttempt()
+
+    def note_of(e):
+        return f"{type(e).__name__}: {e}"[:300]
+
+    try:
+        capture()
+    except Exception as e:                       # capture refused on this rank
+        out.ok, out.note = 0, note_of(e)
+    out.captured = all_ok(out.ok)
+    if not out.captured:
+        drop_graph()
+        return out
+    try:
+        warm_replay()
+    except Exception as e:
+        out.ok, out.note = 0, note_of(e)
+    if not all_ok(out.ok):                       # opening barrier of the timed region
+        drop_graph()
+        return out
+    t0 = clock()
+    try:
+        timed_replay()
+    except Exception as e:
+        out.ok, out.note = 0, note_of(e)
+    out.agreed = all_ok(out.ok)                  # closing barrier: every rank's K steps are done (or some rank gave up)
+    dt = clock() - t0
+    if not out.agreed:
+        drop_graph()
+        return out
+    out.seconds = float(reduce_max(dt))
+    return out

@@ -119,3 +119,79 @@ def test_action_scatter_world2_gloo():
     flags = q.get(timeout=120)
     [p.join(timeout=60) for p in procs]
     assert flags == [True] * world
+
+
+def _negotiate_worker(rank, world, port, fail_rank, fail_phase, q):
+    """One rank of bench.py's --exchange auto attempt with mock capture / replay callables: `fail_rank` raises in `fail_phase`."""
+    from quadruped_gym_amd.dist import make_all_ok, negotiate_graph_replay
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    state = {"graph": None}
+
+    def phase(name):
+        def fn():
+            calls.append(name)
+            if rank == fail_rank and name == fail_phase:
+                raise RuntimeError(f"injected {name} failure on rank {rank}")
+            if name == "capture":
+                state["graph"] = "captured"
+        return fn
+
+    def drop_graph():
+        calls.append("drop")
+        state["graph"] = None
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    att = negotiate_graph_replay(make_all_ok(None, "cpu"), reduce_max, phase("capture"), phase("warm"), phase("timed"), drop_graph)
+    # whatever happened, the ranks are still in step: the eager path's collectives that follow must match up
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    outs = [None] * world
+    dist.all_gather_object(outs, {"captured": att.captured, "agreed": att.agreed, "ok": att.ok, "note": att.note, "seconds": att.seconds,
+                                  "calls": calls, "graph": state["graph"], "sum": float(t.item())})
+    if rank == 0:
+        q.put(outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_phase", ["capture", "warm", "timed", None])
+def test_graph_exchange_agreement_with_one_failing_rank_world2_gloo(fail_phase):
+    """bench.py --exchange auto, the case a one-GPU box cannot produce: rank 1 fails to capture (or to replay) while rank 0 succeeds.
+    Both ranks must leave the attempt on the eager path, in step with each other (no hang, exit status 0, later collectives match);
+    with no failure both agree on the replay's time."""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, world, port, 1, fail_phase, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = q.get(timeout=120)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    r0, r1 = outs
+    assert r0["sum"] == r1["sum"] == 3.0                        # the collective after the attempt matched up
+    assert r0["captured"] == r1["captured"] and r0["agreed"] == r1["agreed"]
+    if fail_phase is None:
+        assert r0["agreed"] and r1["agreed"] and r0["ok"] == r1["ok"] == 1
+        assert r0["seconds"] == r1["seconds"] and np.isfinite(r0["seconds"])     # MAX over ranks
+        assert r0["graph"] == r1["graph"] == "captured" and "drop" not in r0["calls"] + r1["calls"]
+        return
+    assert not r0["agreed"] and not r1["agreed"]
+    assert r0["ok"] == 1 and r0["note"] is None                 # the healthy rank saw no error of its own ...
+    assert r1["ok"] == 0 and "injected" in r1["note"]
+    assert r0["graph"] is None and r1["graph"] is None          # ... and still went back to the eager path
+    assert r0["calls"][-1] == "drop" and r1["calls"][-1] == "drop"
+    assert r0["seconds"] == float("inf")
+    want = {"capture": ["capture", "drop"], "warm": ["capture", "warm", "drop"], "timed": ["capture", "warm", "timed", "drop"]}[fail_phase]
+    assert r0["calls"] == want and r1["calls"] == want          # nobody replays a graph its peer does not hold
+    assert r0["captured"] == (fail_phase != "capture")
