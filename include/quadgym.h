@@ -19,13 +19,15 @@
  * consecutive calls on ONE stream are ordered by that stream, calls on different streams are the
  * caller's to order.  Every other entry point that touches the per-env state (qg_reset,
  * qg_walk_reset, qg_po_reset, the host-pointer qg_step / qg_walk_step / qg_po_step,
- * qg_get_state / qg_set_state, the command and estimate accessors, the destroy calls) first waits
+ * qg_get_state / qg_set_state, the task-layer snapshots, the command and estimate accessors, the destroy calls) first waits
  * for ALL work on the handle's device (hipDeviceSynchronize), runs on the library's own stream and
  * returns when it has completed -- it can therefore follow device-pointer steps on any stream
  * without further synchronisation, and must not be called while a stream is being captured.
  * (The host-pointer steps skip that device-wide wait when no device-pointer call of this handle
  * has gone to a caller's stream since the last one: their own stream is synchronised at the end
- * of every call, so there is nothing to wait for.)
+ * of every call, so there is nothing to wait for.  Once a device-pointer step of the handle has
+ * been captured into a hipGraph the wait is taken on every host-pointer call: replays enqueue
+ * steps the library does not see.)
  *
  * Layouts at the boundary (row-major, env-major -- what NumPy / torch hand over):
  *   actions  [n_envs][12] f32      obs   [n_envs][obs_dim] f32
@@ -264,7 +266,8 @@ typedef struct qg_walk qg_walk;
 
 int qg_walk_default_params(qg_walk_params *out);
 /* Binds the task layer to `sim` (switches its flip termination and data.ctrl tracking on; qg_walk_destroy switches both back
- * to what they were).  Lifetime: a qg_walk borrows its qg_sim and a qg_po borrows its qg_walk -- destroy them in the order
+ * to what they were).  One layer per simulator: a second qg_walk_create on the same sim is refused.  The estimator window
+ * ceil(2 / (min_freq * timestep * frame_skip)) has no upper bound other than memory (math_utils.py:26-28).  Lifetime: a qg_walk borrows its qg_sim and a qg_po borrows its qg_walk -- destroy them in the order
  * po, walk, sim. */
 int qg_walk_create(qg_sim *sim, const qg_walk_params *params, qg_walk **out);
 int qg_walk_destroy(qg_walk *walk);
@@ -297,6 +300,20 @@ int qg_walk_get_commands(qg_walk *walk, float *velocity_xy, float *heading_xy);
 /* Snapshot of the estimator outputs (f_est, a_est: [n][12], host pointers) and the ideal position ([n][2]). */
 int qg_walk_get_estimates(qg_walk *walk, float *f_est, float *a_est, float *ideal_xy);
 
+/* Task-layer snapshot / restore (checkpoint and resume; the reference only resumes the policy,
+ * src/train_quadruped.py:114-141, its env state is rebuilt by reset()).  qg_get_state / qg_set_state cover the physics; these cover what
+ * the walking layer keeps per env beyond it -- commands, ideal position, previous control and its first cost, the derived-term memory,
+ * the whole estimator (ring, block summaries, counters, estimates) -- as ONE opaque blob of qg_walk_state_bytes() bytes (host pointer).
+ * The layout is private to the library version and to (n_envs, window); set_state refuses a blob whose header does not match. */
+int64_t qg_walk_state_bytes(const qg_walk *walk);
+int qg_walk_get_state(qg_walk *walk, void *blob);
+int qg_walk_set_state(qg_walk *walk, const void *blob);
+/* The simulator's reset streams: per-env episode counters [n] and the batch seed, which key every random draw of a (re)set
+ * (random yaw, hinge jitter, commands).  Together with qg_get_state and the blobs a restored run continues bit for bit,
+ * auto-resets included.  Either output may be NULL; a NULL `episode` in the setter leaves the counters as they are. */
+int qg_get_reset_streams(qg_sim *sim, int32_t *episode, uint64_t *seed);
+int qg_set_reset_streams(qg_sim *sim, const int32_t *episode, uint64_t seed);
+
 /* ---- partially observable observation pack ---------------------------------
  * POWalkingQuadrupedEnv (src/envs/po_walking_quad.py:10-90): per step one 26-value frame [gyro 3, accel 3,
  * Madgwick-IMU Euler angles 3, body_vel xy 2, data.ctrl 12, command vx vy theta 3], stacked over obs_window
@@ -317,6 +334,10 @@ int qg_po_reset(qg_po *po, const uint8_t *mask, uint64_t seed, uint32_t flags, f
 int qg_po_step(qg_po *po, const float *actions, float *obs, float *reward, uint8_t *done, float *components, float *terminal_obs);
 int qg_po_step_device(qg_po *po, const float *actions, float *obs, float *reward, uint8_t *done, float *components,
                       float *terminal_obs, void *stream);
+/* Snapshot / restore of the observation pack's own state (orientation estimate, its aliasing flag, the frame ring): as qg_walk_get_state. */
+int64_t qg_po_state_bytes(const qg_po *po);
+int qg_po_get_state(qg_po *po, void *blob);
+int qg_po_set_state(qg_po *po, const void *blob);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,8 @@ struct qg_sim {
     // staging for the host-pointer entry points
     float *d_actions, *d_obs, *d_reward, *d_comps, *d_stage;
     int32_t caller_inflight;  // a device-pointer step has been enqueued on a caller's stream since the last device-wide wait
+    int32_t captured_once;    // a device-pointer step of this handle has been CAPTURED into a hipGraph: replays enqueue steps the library
+                              // never sees, so from then on every host-pointer call takes the device-wide wait (sticky)
     uint8_t *h_pin;           // page-locked staging of the host-pointer entry points (see pin_reserve)
     size_t h_pin_cap;
     uint8_t *d_done, *d_mask;
@@ -103,6 +105,7 @@ extern "C" int64_t qg_time_limit_substeps(double timestep, double max_time) { re
 extern "C" int qg_destroy(qg_sim *s) {
     if (!s) return QG_OK;
     (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();                  // steps may still be in flight on a caller's stream (the header's ordering contract)
     void *ptrs[] = {s->d_model, s->d_task, s->st.qpos, s->st.qvel, s->st.act, s->st.ctrl, s->st.nstep, s->st.episode, s->d_actions,
                     s->d_obs,   s->d_reward, s->d_comps, s->d_stage, s->d_done, s->d_mask};
     for (void *p : ptrs)
@@ -269,7 +272,13 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.env_index_base = s->env_index_base;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     const int emap = effective_mapping(s);
-    if (stream != s->stream) s->caller_inflight = 1;
+    if (stream != s->stream) {
+        s->caller_inflight = 1;
+        if (!s->captured_once) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) s->captured_once = 1;
+        }
+    }
     if (po && !(walk && emap == QG_MAP_LINK)) return fail(QG_ERR_ARG, "launch_step: the fused observation pack needs the one-link-per-lane walking kernel");
     if (walk && emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
@@ -397,7 +406,7 @@ static void pin_out_finish(qg_sim *s, const PinOut &o) {
 // The host-pointer steps must not overtake device-pointer steps still in flight on a caller's stream; a device-wide wait is only
 // needed if one has been enqueued since the last one (the library's own stream is synchronised at the end of every host-pointer call).
 static int wait_for_caller_streams(qg_sim *s) {
-    if (!s->caller_inflight) return QG_OK;
+    if (!s->caller_inflight && !s->captured_once) return QG_OK;
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     s->caller_inflight = 0;
     return QG_OK;
@@ -703,6 +712,7 @@ struct qg_walk {
     KWalkState st;
     float *d_obs, *d_reward, *d_comps, *d_actions, *d_tmp;
     uint8_t *d_done;
+    size_t ring_slots, summary_blocks;      // allocated extent of the estimator's ring (whole blocks) and of its block summaries
 };
 
 // The walking env-step is ONE launch with every mapping AUTO can pick -- the task layer is fused into the one-link-per-lane, the
@@ -755,6 +765,9 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     if (!s || !out) return fail(QG_ERR_ARG, "qg_walk_create: null argument");
     *out = nullptr;
     if (s->obs_dim != QG_NSENSOR) return fail(QG_ERR_ARG, "qg_walk_create: the walking rewards read the 33-value sensordata (obs_mode QG_OBS_FULL)");
+    // one task layer per simulator: a second one would save the flags the first has already switched (flip termination, data.ctrl
+    // tracking) as "what the sim had", and whichever is destroyed first would switch them off under the other
+    if (s->walk_bound) return fail(QG_ERR_ARG, "qg_walk_create: a walking task layer is already bound to this simulator (destroy it first)");
     qg_walk_params dp;
     if (!params) { qg_walk_default_params(&dp); params = &dp; }
     if (!(params->min_freq > 0) || !(params->ema_alpha >= 0 && params->ema_alpha <= 1)) return fail(QG_ERR_ARG, "qg_walk_create: bad estimator parameters");
@@ -771,9 +784,13 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     int64_t settle = params->settling_time > 0 ? qg_time_limit_substeps_impl(s->model.timestep, params->settling_time) : 0;
     k.settle_substeps = (int32_t)(settle > INT32_MAX ? INT32_MAX : settle);
     k.window = (int32_t)std::ceil(2.0 / (params->min_freq * dt));   // math_utils.py:26-28
-    if (k.window < 1 || k.window > QG_WALK_MAXBLOCKS * QG_WALK_BLOCK) {
-        delete w;
-        return fail(QG_ERR_ARG, "qg_walk_create: estimator window %d outside 1..%d samples (min_freq * timestep * frame_skip too small)", k.window, QG_WALK_MAXBLOCKS * QG_WALK_BLOCK);
+    {   // the reference puts no upper bound on the window (frame_skip 1 / 2 / 3 at the shipped timestep: 1000 / 500 / 334 samples);
+        // only memory does: the ring holds window x 12 x n_envs samples
+        const double w_exact = std::ceil(2.0 / (params->min_freq * dt));
+        if (!(w_exact >= 1) || w_exact > 1e6) {
+            delete w;
+            return fail(QG_ERR_ARG, "qg_walk_create: estimator window %g outside 1..1000000 samples (min_freq * timestep * frame_skip)", w_exact);
+        }
     }
     k.ema_alpha = (float)params->ema_alpha;
     k.control_cost_alpha = (float)params->control_cost_alpha;
@@ -802,7 +819,9 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     {   // the ring in whole blocks and all 16 summary slots, whatever the window: the estimator's loads are unconditional
         const size_t nb = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK, Wp = nb * QG_WALK_BLOCK;
         WALLOC(w->st.sig, Wp * 12 * n * 4); WALLOC(w->st.cross, Wp * 12 * n);
-        WALLOC(w->st.bmax, (size_t)QG_WALK_MAXBLOCKS * 12 * n * 4); WALLOC(w->st.bmin, (size_t)QG_WALK_MAXBLOCKS * 12 * n * 4);
+        const size_t nbs = nb > QG_WALK_MAXBLOCKS ? nb : QG_WALK_MAXBLOCKS;     // at least the 16 slots the unrolled rebuild reads
+        w->ring_slots = Wp; w->summary_blocks = nbs;
+        WALLOC(w->st.bmax, nbs * 12 * n * 4); WALLOC(w->st.bmin, nbs * 12 * n * 4);
         WALLOC(w->st.smax, (size_t)QG_WALK_BLOCK * 12 * n * 4); WALLOC(w->st.smin, (size_t)QG_WALK_BLOCK * 12 * n * 4);
     }
     WALLOC(w->st.omax, 12 * n * 4); WALLOC(w->st.omin, 12 * n * 4); WALLOC(w->st.count, 12 * n * 4);
@@ -1002,6 +1021,100 @@ extern "C" int qg_walk_get_estimates(qg_walk *w, float *f_est, float *a_est, flo
     return QG_OK;
 }
 
+// ---- task-layer snapshot / restore (checkpoint) -------------------------------------------------------------
+// One opaque blob per layer: a header that pins what the bytes mean (layer, library layout version, n_envs, window) followed by the
+// layer's device arrays in declaration order, byte for byte.  Restoring a blob into a layer of the same shape reproduces every later
+// step bit for bit (tests/test_walking_gpu.py::test_task_state_snapshot_restores_bit_identical_rollouts).
+struct QgBlobHeader { uint32_t magic, version; int32_t n, window; int64_t bytes; };
+#define QG_BLOB_WALK 0x4b4c5751u   /* "QWLK" */
+#define QG_BLOB_PO 0x4f505751u     /* "QWPO" */
+#define QG_BLOB_VERSION 3u
+struct QgField { void *ptr; size_t bytes; };
+
+static int walk_fields(const qg_walk *w, QgField *f) {
+    const size_t n = (size_t)w->sim->n, R = w->ring_slots, NB = w->summary_blocks;
+    const KWalkState &S = w->st;
+    const QgField all[] = {
+        {S.vel, 2 * n * 4}, {S.head, 2 * n * 4}, {S.gvel, 2 * n * 4}, {S.ideal, 2 * n * 4}, {S.prev_ctrl, 12 * n * 4}, {S.prev_ctrl_cost, n * 4},
+        {S.has_ctrl_cost, n}, {S.prev_derive, n * 4}, {S.has_derive, n}, {S.calls, n * 4}, {S.sig, R * 12 * n * 4}, {S.cross, R * 12 * n},
+        {S.bmax, NB * 12 * n * 4}, {S.bmin, NB * 12 * n * 4}, {S.smax, (size_t)QG_WALK_BLOCK * 12 * n * 4}, {S.smin, (size_t)QG_WALK_BLOCK * 12 * n * 4},
+        {S.omax, 12 * n * 4}, {S.omin, 12 * n * 4}, {S.count, 12 * n * 4}, {S.prev, 12 * n * 4}, {S.sign, 12 * n * 4}, {S.f_est, 12 * n * 4},
+        {S.a_est, 12 * n * 4}, {S.eff_actions, 12 * n * 4}};
+    const int k = (int)(sizeof all / sizeof all[0]);
+    if (f) memcpy(f, all, sizeof all);
+    return k;
+}
+#define QG_MAX_FIELDS 32
+static int64_t blob_bytes(const QgField *f, int k) {
+    size_t b = sizeof(QgBlobHeader);
+    for (int i = 0; i < k; i++) b += f[i].bytes;
+    return (int64_t)b;
+}
+static int blob_out(qg_sim *s, uint32_t magic, int32_t window, const QgField *f, int k, void *blob) {
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps may be in flight on a caller's stream
+    QgBlobHeader h = {magic, QG_BLOB_VERSION, s->n, window, blob_bytes(f, k)};
+    uint8_t *p = (uint8_t *)blob;
+    memcpy(p, &h, sizeof h);
+    p += sizeof h;
+    for (int i = 0; i < k; i++) {
+        HIP_TRY(hipMemcpy(p, f[i].ptr, f[i].bytes, hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+        p += f[i].bytes;
+    }
+    return QG_OK;
+}
+static int blob_in(qg_sim *s, uint32_t magic, int32_t window, const QgField *f, int k, const void *blob, const char *who) {
+    QgBlobHeader h;
+    memcpy(&h, blob, sizeof h);
+    if (h.magic != magic || h.version != QG_BLOB_VERSION) return fail(QG_ERR_ARG, "%s: not a snapshot of this layer / library version", who);
+    if (h.n != s->n || h.window != window || h.bytes != blob_bytes(f, k))
+        return fail(QG_ERR_ARG, "%s: the snapshot was taken from %d envs with window %d (%lld bytes); this layer has %d envs, window %d (%lld bytes)", who,
+                    h.n, h.window, (long long)h.bytes, s->n, window, (long long)blob_bytes(f, k));
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    const uint8_t *p = (const uint8_t *)blob + sizeof h;
+    for (int i = 0; i < k; i++) {
+        HIP_TRY(hipMemcpy(f[i].ptr, p, f[i].bytes, hipMemcpyHostToDevice), QG_ERR_DEVICE);
+        p += f[i].bytes;
+    }
+    return QG_OK;
+}
+
+extern "C" int64_t qg_walk_state_bytes(const qg_walk *w) {
+    if (!w) return fail(QG_ERR_ARG, "null handle");
+    QgField f[QG_MAX_FIELDS];
+    return blob_bytes(f, walk_fields(w, f));
+}
+extern "C" int qg_walk_get_state(qg_walk *w, void *blob) {
+    if (!w || !blob) return fail(QG_ERR_ARG, "qg_walk_get_state: null argument");
+    QgField f[QG_MAX_FIELDS];
+    return blob_out(w->sim, QG_BLOB_WALK, w->kp.window, f, walk_fields(w, f), blob);
+}
+extern "C" int qg_walk_set_state(qg_walk *w, const void *blob) {
+    if (!w || !blob) return fail(QG_ERR_ARG, "qg_walk_set_state: null argument");
+    QgField f[QG_MAX_FIELDS];
+    return blob_in(w->sim, QG_BLOB_WALK, w->kp.window, f, walk_fields(w, f), blob, "qg_walk_set_state");
+}
+
+// the reset streams of the simulator itself: the per-env episode counters and the batch seed that key every random draw of a
+// (re)set -- what qg_get_state does not cover and a bit-exact resume under auto-reset needs
+extern "C" int qg_get_reset_streams(qg_sim *s, int32_t *episode, uint64_t *seed) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    if (episode) HIP_TRY(hipMemcpy(episode, s->st.episode, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost), QG_ERR_DEVICE);
+    if (seed) *seed = s->seed;
+    return QG_OK;
+}
+extern "C" int qg_set_reset_streams(qg_sim *s, const int32_t *episode, uint64_t seed) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    if (episode) HIP_TRY(hipMemcpy(s->st.episode, episode, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice), QG_ERR_DEVICE);
+    s->seed = seed;
+    return QG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // partially observable observation pack (qg_po.hip)
 // ------------------------------------------------------------------------------------------------------
@@ -1015,6 +1128,7 @@ struct qg_po {
 extern "C" int qg_po_destroy(qg_po *p) {
     if (!p) return QG_OK;
     (void)hipSetDevice(p->walk->sim->device);
+    (void)hipDeviceSynchronize();                  // steps that read or write the frame ring may still be in flight on a caller's stream
     void *ptrs[] = {p->st.orient, p->st.alias, p->st.nstep, p->st.stack, p->st.head, p->d_obs33, p->d_out, p->d_term};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -1155,4 +1269,27 @@ extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *rew
         if (any) HIP_TRY(hipMemcpy(terminal_obs, p->d_term, n * width * 4, hipMemcpyDeviceToHost), QG_ERR_DEVICE);
     }
     return QG_OK;
+}
+
+static int po_fields(const qg_po *p, QgField *f) {
+    const size_t n = (size_t)p->walk->sim->n, width = (size_t)p->kp.window * QG_PO_FRAME;
+    const QgField all[] = {{p->st.orient, 4 * n * 4}, {p->st.alias, n}, {p->st.nstep, n * 4}, {p->st.stack, n * width * 4}, {p->st.head, n * 4}};
+    const int k = (int)(sizeof all / sizeof all[0]);
+    if (f) memcpy(f, all, sizeof all);
+    return k;
+}
+extern "C" int64_t qg_po_state_bytes(const qg_po *p) {
+    if (!p) return fail(QG_ERR_ARG, "null handle");
+    QgField f[QG_MAX_FIELDS];
+    return blob_bytes(f, po_fields(p, f));
+}
+extern "C" int qg_po_get_state(qg_po *p, void *blob) {
+    if (!p || !blob) return fail(QG_ERR_ARG, "qg_po_get_state: null argument");
+    QgField f[QG_MAX_FIELDS];
+    return blob_out(p->walk->sim, QG_BLOB_PO, p->kp.window, f, po_fields(p, f), blob);
+}
+extern "C" int qg_po_set_state(qg_po *p, const void *blob) {
+    if (!p || !blob) return fail(QG_ERR_ARG, "qg_po_set_state: null argument");
+    QgField f[QG_MAX_FIELDS];
+    return blob_in(p->walk->sim, QG_BLOB_PO, p->kp.window, f, po_fields(p, f), blob, "qg_po_set_state");
 }

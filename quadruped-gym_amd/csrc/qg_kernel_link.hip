@@ -91,7 +91,7 @@ template <bool BAKED>
 DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env, BaseState &B, HingeLane &J, const LinkRegs &K,
                       bool want_sensors, float *__restrict__ row, int kleg, float &zaxis_z) {
     const float h = C.h;
-    const BaseCtx bc = base_prelude(C, B);
+    const BaseCtx bc = base_prelude<true>(C, B);     // the quaternion is of unit length here (normalised at load, then by base_integrate)
     const V3 nb = bc.n;
     if (want_sensors) {              // the step's sensordata describes the state at the start of its last substep
         zaxis_z = bc.cz.z;
@@ -207,7 +207,8 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     fc.l = v3(leg_suffix(f.l.x), leg_suffix(f.l.y), leg_suffix(f.l.z));
     // ---- column r of the leg's joint block, the joint's own terms -------------------------------------------------------------------
     const SV F = mul(Ic, So);
-    const float Hc0 = dot(S[0], F), Hc1 = dot(S[1], F), Hc2 = dot(S[2], F);
+    const float Hc0 = dot(S[0], F), Hc1 = dot(S[1], F);          // rows 0, 1 of column r (used by the lanes below the diagonal only)
+    const float Hown = dot(So, F);                                // the diagonal entry
     const float tb = dot(So, fc);
     float Hd_o, b_o;
     {
@@ -230,7 +231,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         const float lim_a = free_a ? 0.f : tq_a, be_a = free_a ? -spring_a * rcp(qd) : bl;
         tau = tau + (is_below ? lim_b : 0.f) - (is_above ? lim_a : 0.f);
         dimp = dimp + (is_below ? be_b : (is_above ? be_a : 0.f));
-        Hd_o = sel3(rr, Hc0, Hc1, Hc2) + K.armature + h * dimp;
+        Hd_o = Hown + K.armature + h * dimp;
         b_o = tau - tb;
     }
     // ---- the 3x3 block and its right-hand side in every lane of the leg; LDL^T ----------------------------------------------------------
@@ -276,29 +277,29 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     // right-hand side share: -(f_own + z_r y_r / d_r)
     SV rhn = {v3(fmaf(-yr, w[0], -f.a.x), fmaf(-yr, w[1], -f.a.y), fmaf(-yr, w[2], -f.a.z)),
               v3(fmaf(-yr, w[3], -f.l.x), fmaf(-yr, w[4], -f.l.y), fmaf(-yr, w[5], -f.l.z))};
-    // ---- base block: FRAME body + contact first (a wave-uniform branch), then the sums over the env's 16 lanes and the 6x6 solve, all
-    // redundant in the 16 lanes.  The sums come after the branch so that each DPP move sits in one basic block with the add that
-    // consumes it (the compiler fuses them into v_add_f32_dpp only then).
+    // ---- base block: FRAME body, the sums over the env's 16 lanes, the FRAME's contact (a wave-uniform branch that updates the block
+    // in place: on the usual path, no contact, nothing has to be moved), the 6x6 solve -- all redundant in the 16 lanes.  Every DPP
+    // move sits in one basic block with the add that consumes it (the compiler fuses them into v_add_f32_dpp only then).
     float x6[6];
     {
         SV p0;
         Sym6 Ic0;
         frame_body(C, bc, h, p0, Ic0);
         wsumF = env_sum(wsumF);
-        if (__any(wsumF > 0.f)) {         // wave-uniform skip, as in the one-leg-per-lane kernel
-            sF = env_sum(sF);
-            Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-            SV fe;
-            contact_finish(wsumF, sF, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
-            p0.a = p0.a - fe.a;
-            p0.l = p0.l - fe.l;
-        }
         Ic0.AA.xx += env_sum(Cn.AA.xx); Ic0.AA.yy += env_sum(Cn.AA.yy); Ic0.AA.zz += env_sum(Cn.AA.zz);
         Ic0.AA.xy += env_sum(Cn.AA.xy); Ic0.AA.xz += env_sum(Cn.AA.xz); Ic0.AA.yz += env_sum(Cn.AA.yz);
         Ic0.AL.r0 = Ic0.AL.r0 + env_sum(Cn.AL.r0); Ic0.AL.r1 = Ic0.AL.r1 + env_sum(Cn.AL.r1); Ic0.AL.r2 = Ic0.AL.r2 + env_sum(Cn.AL.r2);
         Ic0.LL.xx += env_sum(Cn.LL.xx); Ic0.LL.yy += env_sum(Cn.LL.yy); Ic0.LL.zz += env_sum(Cn.LL.zz);
         Ic0.LL.xy += env_sum(Cn.LL.xy); Ic0.LL.xz += env_sum(Cn.LL.xz); Ic0.LL.yz += env_sum(Cn.LL.yz);
         SV b = {env_sum(rhn.a) - p0.a, env_sum(rhn.l) - p0.l};
+        if (__any(wsumF > 0.f)) {         // wave-uniform skip, as in the one-leg-per-lane kernel
+            sF = env_sum(sF);
+            Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
+            SV fe;
+            contact_finish(wsumF, sF, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
+            b.a = b.a + fe.a;
+            b.l = b.l + fe.l;
+        }
         base_solve(Ic0, b, x6);
     }
     const V3 wdot = v3(x6[0], x6[1], x6[2]);
@@ -319,7 +320,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         hinge_advance(h * J.qd, J.sn, J.cs);
         J.act = fmaf(J.u - J.act, K.act_decay, J.act);
     }
-    base_integrate(bc, h, wdot, acl, B);
+    base_integrate<true>(bc, h, wdot, acl, B);
 }
 
 // Workgroups of four waves (one per SIMD of a CU): a grid of 1024 one-wave workgroups measured 1.65 us more fixed time per launch
@@ -378,7 +379,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         const KLink &L0 = C.link[0], &L1 = C.link[1], &L2 = C.link[2];
         const KLink &Lown = C.link[3 * k + rk];     // !BAKED: this lane's own link, read from the staged table
         const float ml = r < 3 ? 1.f : 0.f;
-#define QG_SEL(field) (BAKED ? sel3(rk, L0.field, L1.field, L2.field) : Lown.field)
+        // picked with multiply-adds on 0 / 1 lane masks (exact: x * 1 + 0): three instructions per value with the literals folded into
+        // v_mul / v_fmamk, against mov + cndmask + mov + cndmask (a VOP3 select takes no literal)
+        const float s0 = rk == 0 ? 1.f : 0.f, s1 = rk == 1 ? 1.f : 0.f, s2 = rk == 2 ? 1.f : 0.f;
+#define QG_SEL(field) (BAKED ? fmaf(s2, L2.field, fmaf(s1, L1.field, s0 * L0.field)) : Lown.field)
         K.mass = ml * QG_SEL(mass);
 #pragma unroll
         for (int i = 0; i < 3; ++i) K.ipos[i] = QG_SEL(ipos[i]);
@@ -406,6 +410,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
     B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised
+        const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
+        B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
+    }
     const int nstep0 = P.st.nstep[env];
     // this lane's hinge (the spare lane shadows hinge 2 of its leg: same loads, nothing of it is ever stored)
     const int rk = r < 3 ? r : 2;

@@ -385,10 +385,16 @@ struct BaseCtx {
     V3 n, gb, vb;           // world up, gravity and base linear velocity in FRAME axes
     SV V0, A0;              // spatial velocity of the FRAME; its spatial acceleration when the unknowns are zero
 };
+// UNIT: the caller guarantees a quaternion of unit length (the one-link-per-lane kernel normalises the loaded state once per launch;
+// base_integrate hands a normalised quaternion from substep to substep) -- 13 instructions per substep that only repeated it.
+template <bool UNIT = false>
 DEV BaseCtx base_prelude(const KModel &C, const BaseState &B) {
     BaseCtx c;
-    float qn = rcp(__builtin_amdgcn_sqrtf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz));
-    float w = B.qw * qn, x = B.qx * qn, y = B.qy * qn, z = B.qz * qn;
+    float w = B.qw, x = B.qx, y = B.qy, z = B.qz;
+    if constexpr (!UNIT) {
+        float qn = rcp(__builtin_amdgcn_sqrtf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz));
+        w = B.qw * qn; x = B.qx * qn; y = B.qy * qn; z = B.qz * qn;
+    }
     c.w = w; c.x = x; c.y = y; c.z = z;
     c.cx = v3(1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y));
     c.cy = v3(2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x));
@@ -676,6 +682,8 @@ DEV void base_solve(const Sym6 &Ic0, SV rhs, float x6[6]) {
 }
 
 // semi-implicit integration of the base: velocity, then position / quaternion with the NEW velocity
+// RSQ: one v_rsq_f32 (1 ulp) for the final normalisation instead of v_sqrt_f32 + v_rcp_f32
+template <bool RSQ = false>
 DEV void base_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B) {
     // d/dt v_world = R * (classical acceleration in FRAME axes)
     V3 aw = fma3(acl.x, c.cx, fma3(acl.y, c.cy, acl.z * c.cz));
@@ -693,7 +701,8 @@ DEV void base_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B
     float nx = w * dv.x + x * cw + y * dv.z - z * dv.y;
     float ny = w * dv.y - x * dv.z + y * cw + z * dv.x;
     float nz = w * dv.z + x * dv.y - y * dv.x + z * cw;
-    float inv = rcp(__builtin_amdgcn_sqrtf(nw * nw + nx * nx + ny * ny + nz * nz));
+    const float n2 = nw * nw + nx * nx + ny * ny + nz * nz;
+    float inv = RSQ ? __builtin_amdgcn_rsqf(n2) : rcp(__builtin_amdgcn_sqrtf(n2));
     B.qw = nw * inv; B.qx = nx * inv; B.qy = ny * inv; B.qz = nz * inv;
 }
 
@@ -1036,6 +1045,7 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         SV p0;
         Sym6 Ic0;
         frame_body(C, bc, h, p0, Ic0);
+        SV b;
         {   // FRAME contact: this lane evaluates its quarter turn of the three base sample points
             float wsum = 0.f;
             V3 s = v3(0.f, 0.f, 0.f);
@@ -1050,21 +1060,24 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
                 }
             }
             wsum = quad_sum(wsum);
+            add(Ic0, Ic);
+            b.a = v3(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a;
+            b.l = v3(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l;
             // Wave-uniform skip: under actuation the robot stands on its feet and the FRAME practically never touches the
             // floor; when no env of the wave has a FRAME sample point below the margin every term below is exactly zero.
             // (A/B on one box: +3.4 % at 4096 envs, +6.5 % at 262 144.  The same skip per leg link does NOT pay: a taken
             // branch over a large block stalls the instruction fetch of a wave that is alone on its SIMD.)
+            // The branch updates the assembled block IN PLACE (round 3): with the block assembled after it, the usual path -- no
+            // contact -- had to materialise the FRAME's constant entries as the other arm of a phi, 17 moves per substep.
             if (__any(wsum > 0.f)) {
                 s = quad_sum(s);
                 Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
                 SV fe;
                 contact_finish(wsum, s, E0, v3(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
-                p0.a = p0.a - fe.a;
-                p0.l = p0.l - fe.l;
+                b.a = b.a + fe.a;
+                b.l = b.l + fe.l;
             }
         }
-        add(Ic0, Ic);
-        SV b = {v3(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a, v3(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l};
         base_solve(Ic0, b, x6);
     }
     V3 wdot = v3(x6[0], x6[1], x6[2]);
@@ -1440,6 +1453,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
         SV p0;
         Sym6 Ic0;
         frame_body(C, bc, h, p0, Ic0);
+        SV b;
         {   // FRAME contact: this lane evaluates two quarter turns of the three base sample points
             f2 wsum2 = f2(0.f);
             V3T<f2> s2 = v3<f2>(f2(0.f), f2(0.f), f2(0.f));
@@ -1451,17 +1465,18 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
                 contact_point(v3<f2>(cm * r0.x - sm * r0.y, sm * r0.x + cm * r0.y, f2(r0.z)), n2, zb, wsum2, s2);
             }
             float wsum = pair_sum(hsum(wsum2));
-            if (__any(wsum > 0.f)) {        // wave-uniform skip, as in the quad kernel
+            add(Ic0, Ic);
+            b.a = v3<float>(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a;
+            b.l = v3<float>(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l;
+            if (__any(wsum > 0.f)) {        // wave-uniform skip, as in the quad kernel (the block is updated in place)
                 V3 s = pair_sum(hsum(s2));
                 Fr E0 = {v3<float>(1.f, 0.f, 0.f), v3<float>(0.f, 1.f, 0.f), v3<float>(0.f, 0.f, 1.f)};
                 SV fe;
                 contact_finish<float>(wsum, s, E0, v3<float>(0.f, 0.f, 0.f), bc.n, bc.V0, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, Ic0);
-                p0.a = p0.a - fe.a;
-                p0.l = p0.l - fe.l;
+                b.a = b.a + fe.a;
+                b.l = b.l + fe.l;
             }
         }
-        add(Ic0, Ic);
-        SV b = {v3<float>(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a, v3<float>(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l};
         base_solve(Ic0, b, x6);
     }
     V3 wdot = v3<float>(x6[0], x6[1], x6[2]);

@@ -132,7 +132,7 @@ template <int NCH> __device__ __forceinline__ void walk_stv(int *p, const int (&
         for (int c = 0; c < NCH; ++c) p[c] = v[c];
     }
 }
-#define QG_WALK_MAXBLOCKS 16              // the ring buffer and its summaries are allocated for 16 blocks (window <= 256 samples)
+#define QG_WALK_MAXBLOCKS 16              // block summaries read by the unrolled rebuild (windows up to 256 samples); longer windows add a rolled loop
 #define QG_WALK_EMPTY_MAX (-3.0e38f)      // "nothing there" (finite: the device pass is compiled with -ffinite-math-only)
 #define QG_WALK_EMPTY_MIN (3.0e38f)
 template <int NCH> struct WalkEstIn {
@@ -176,12 +176,25 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
         // (a) the cache of the other blocks is rebuilt from the summaries
         float hi[NCH][QG_WALK_MAXBLOCKS], lo[NCH][QG_WALK_MAXBLOCKS];
 #pragma unroll
-        for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // every summary slot exists (16 blocks are allocated whatever the window): plain loads ...
+        for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // every summary slot exists (at least 16 blocks are allocated whatever the window): plain loads ...
             float h[NCH], l[NCH];
             walk_ldv<NCH>(S.bmax + (size_t)b * stride + t0, h);
             walk_ldv<NCH>(S.bmin + (size_t)b * stride + t0, l);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { hi[c][b] = h[c]; lo[c][b] = l[c]; }
+        }
+        // windows of more than 256 samples (frame_skip 1 - 3 at the reference's 2 ms timestep: 1000 / 500 / 334): the summaries
+        // past the sixteenth in a rolled loop -- a chain of loads, but only on every sixteenth call and only for such windows
+        float xm[NCH], xn[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { xm[c] = QG_WALK_EMPTY_MAX; xn[c] = QG_WALK_EMPTY_MIN; }
+        for (int b = QG_WALK_MAXBLOCKS; b < nblocks; ++b) {
+            float h[NCH], l[NCH];
+            walk_ldv<NCH>(S.bmax + (size_t)b * stride + t0, h);
+            walk_ldv<NCH>(S.bmin + (size_t)b * stride + t0, l);
+            const bool use = b != bidx && b * QG_WALK_BLOCK < samples;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { xm[c] = fmaxf(xm[c], use ? h[c] : QG_WALK_EMPTY_MAX); xn[c] = fminf(xn[c], use ? l[c] : QG_WALK_EMPTY_MIN); }
         }
         // (b) the block's old samples: the ring is allocated in whole blocks, so the 16 loads are unconditional
         float old[NCH][QG_WALK_BLOCK];
@@ -193,7 +206,7 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
             for (int c = 0; c < NCH; ++c) old[c][j] = o[c];
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) { in.om[c] = QG_WALK_EMPTY_MAX; in.on[c] = QG_WALK_EMPTY_MIN; }
+        for (int c = 0; c < NCH; ++c) { in.om[c] = xm[c]; in.on[c] = xn[c]; }
 #pragma unroll
         for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // ... then selects
             const bool use = b < nblocks && b != bidx && b * QG_WALK_BLOCK < samples;      // blocks that hold at least one filled slot

@@ -5,7 +5,9 @@ The VecEnv protocol hands back one dict per env and step (`infos[i]` = the refer
 thirty times the kernel, the transfers and everything else in ``step()`` together -- while the consumers of ``infos`` (SB3's rollout
 collection, ``VecMonitor``, the reference's ``RewardCallback``) look at the finished envs or at a few entries.  ``LazyInfos`` IS a
 ``list`` (``isinstance`` checks, ``len``, indexing, slicing, iteration, in-place edits of ``infos[i]`` all behave) whose dicts come
-into existence when they are first touched; what is never touched is never built.  The arrays of the step (component rows,
+into existence when they are first touched; what is never touched is never built.  Operations of ``list`` that work on the raw
+storage as a whole (``+`` from either side, ``*``, ``pop``, ``sort``, ``reverse``, ``remove``, ``insert``, ``append`` / ``extend``,
+``del``, slice assignment) first build every dict, so none of them can hand out or move around an unbuilt slot.  The arrays of the step (component rows,
 terminal observations) are captured, not copied per env.
 """
 from __future__ import annotations
@@ -86,3 +88,65 @@ class LazyInfos(list):
 
     def count(self, item):
         return self.materialize().count(item)
+
+    # -- inherited operations that work on the raw storage: build everything first, then let ``list`` do it --------------------------
+    def _fill(self):
+        for i in range(list.__len__(self)):
+            self._get(i)
+
+    def __radd__(self, other):
+        return list(other) + self.materialize()
+
+    def __mul__(self, k):
+        return self.materialize() * k
+
+    __rmul__ = __mul__
+
+    def __iadd__(self, other):
+        self._fill()
+        list.extend(self, other)
+        return self
+
+    def __imul__(self, k):
+        self._fill()
+        return list.__imul__(self, k)
+
+    def pop(self, *args):
+        self._fill()
+        return list.pop(self, *args)
+
+    def remove(self, item):
+        self._fill()
+        list.remove(self, item)
+
+    def insert(self, i, item):
+        self._fill()
+        list.insert(self, i, item)
+
+    def append(self, item):
+        self._fill()
+        list.append(self, item)
+
+    def extend(self, other):
+        self._fill()
+        list.extend(self, other)
+
+    def sort(self, *args, **kw):
+        self._fill()
+        list.sort(self, *args, **kw)
+
+    def reverse(self):
+        self._fill()
+        list.reverse(self)
+
+    def __delitem__(self, i):
+        self._fill()
+        list.__delitem__(self, i)
+
+    def __setitem__(self, i, v):
+        if isinstance(i, slice):
+            self._fill()
+        list.__setitem__(self, i, v)
+
+    def clear(self):
+        list.clear(self)

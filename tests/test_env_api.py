@@ -317,6 +317,22 @@ def test_lazy_infos_is_a_list_of_dicts_built_on_demand():
     assert infos == plain and not (infos != plain) and list(reversed(infos))[0]["i"] == 5
     assert pickle.loads(pickle.dumps(infos)) == plain and copy.deepcopy(infos) == plain and type(copy.deepcopy(infos)) is list
     assert repr(infos) == repr(plain) and infos.copy() == plain and plain[3] in infos
+    # operations list implements on its raw storage must not leak an unbuilt slot (None) either
+    def fresh():
+        return LazyInfos(4, lambda i: {"i": i})
+    want = [{"i": i} for i in range(4)]
+    assert [] + fresh() == want and fresh() + [] == want and fresh() * 1 == want and 2 * fresh() == want + want
+    assert fresh().pop() == {"i": 3} and fresh().pop(0) == {"i": 0}
+    a = fresh(); a.reverse(); assert list(a) == want[::-1]
+    a = fresh(); a.sort(key=lambda d: -d["i"]); assert list(a) == want[::-1]
+    a = fresh(); a.remove({"i": 1}); assert list(a) == [want[0], want[2], want[3]]
+    a = fresh(); a.insert(1, {"x": 1}); assert list(a) == [want[0], {"x": 1}] + want[1:]
+    a = fresh(); a.append({"x": 1}); a.extend([{"y": 2}]); a += [{"z": 3}]; assert list(a) == want + [{"x": 1}, {"y": 2}, {"z": 3}]
+    a = fresh(); del a[1]; assert list(a) == [want[0], want[2], want[3]]
+    a = fresh(); a[1:3] = [{"x": 1}]; assert list(a) == [want[0], {"x": 1}, want[3]]
+    a = fresh(); a *= 2; assert list(a) == want + want
+    a = fresh(); a[2] = {"x": 1}; assert a[2] == {"x": 1} and a[3] == want[3]
+    assert None not in list.__iter__(fresh() + []) and all(d is not None for d in fresh()[::-1])
 
 
 @pytest.mark.gpu
