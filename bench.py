@@ -423,6 +423,8 @@ def main():
     def make_line(dt, kernel_ms, exchange_mode):
         # HBM traffic per launch: committed rocprofv3 PMC measurement of this same configuration, when there is one
         traffic, valu, flops = None, None, None
+        stale, prof_id = None, None
+        build_id = _abi.load_library().qg_build_id().decode()
         try:
             key = f"{MAP_KEY[sim.mapping]}_n{n}_fs{args.frame_skip}_obs{od}"
             with open(os.path.join(ROOT, "profiles", "traffic_index.json")) as fh:
@@ -431,10 +433,16 @@ def main():
             if ent:
                 traffic = ent["hbm_bytes_per_launch"]
                 valu = ent.get("valu_insts_per_wave")
+                # the counters are a committed measurement of this configuration, not of this run: flag an entry that was taken
+                # on other sources than the library now loaded (entries are stamped by tools/update_traffic_index.py)
+                prof_id = ent.get("build_id")
+                stale = prof_id != build_id
             # counted FP32 flops per env-step (SQ_INSTS_VALU_FLOPS_FP32 of the step kernel / envs; FMA = 2): a property of the
             # kernel's instruction stream per substep, so the entry of the same mapping and frame_skip serves every batch size
             fkey = f"flops_{MAP_KEY[sim.mapping]}_fs{args.frame_skip}"
             flops = idx.get(fkey)
+            if flops is not None and flops.get("build_id") != build_id:
+                stale = True
         except Exception:
             pass
         total_envs = n * world
@@ -459,7 +467,8 @@ def main():
             "substeps_per_sec": value * args.frame_skip,
             "state_finite": healthy,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": MAP_KERNEL[sim.mapping],
+                         "traffic": traffic, "profile_stale": stale, "profile_build_id": prof_id, "build_id": build_id,
+                         "kernel": MAP_KERNEL[sim.mapping],
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_step * n,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "VALU-issue-bound path (no dense contraction): ~0.6 KB of state traffic per env-step against "

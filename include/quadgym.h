@@ -141,6 +141,9 @@ typedef struct qg_task {
 typedef struct qg_sim qg_sim;  /* opaque */
 
 const char *qg_version(void);
+/* 16 hex digits: hash of the sources this library was built from (kernels, C ABI, model tables).  Measurement tooling stamps
+ * committed profiles with it; bench.py flags a roofline entry that was measured on other sources (roofline.profile_stale). */
+const char *qg_build_id(void);
 const char *qg_last_error(void);
 
 /* Fill with the constants compiled from the reference model (include/qg_model_data.h). */

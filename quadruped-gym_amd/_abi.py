@@ -153,6 +153,8 @@ def load_library():
     vp, u8p, fp, i32p = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32)
     lib.qg_version.restype = C.c_char_p
     lib.qg_version.argtypes = []
+    lib.qg_build_id.restype = C.c_char_p
+    lib.qg_build_id.argtypes = []
     lib.qg_last_error.restype = C.c_char_p
     lib.qg_last_error.argtypes = []
     lib.qg_default_model.argtypes = [C.POINTER(QgModel)]
@@ -198,10 +200,20 @@ def load_library():
     lib.qg_po_obs_dim.argtypes = [vp]
     lib.qg_po_reset.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
     lib.qg_po_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.qg_walk_state_bytes.restype = C.c_int64
+    lib.qg_walk_state_bytes.argtypes = [vp]
+    lib.qg_walk_get_state.argtypes = [vp, vp]
+    lib.qg_walk_set_state.argtypes = [vp, vp]
+    lib.qg_po_state_bytes.restype = C.c_int64
+    lib.qg_po_state_bytes.argtypes = [vp]
+    lib.qg_po_get_state.argtypes = [vp, vp]
+    lib.qg_po_set_state.argtypes = [vp, vp]
+    lib.qg_get_reset_streams.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+    lib.qg_set_reset_streams.argtypes = [vp, vp, C.c_uint64]
     lib.qg_po_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("qg_version", "qg_last_error", "qg_time_limit_substeps"):
+        if name not in ("qg_version", "qg_build_id", "qg_last_error", "qg_time_limit_substeps", "qg_walk_state_bytes", "qg_po_state_bytes"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -209,7 +221,7 @@ def load_library():
 
 # every symbol include/quadgym.h declares
 EXPORTS = (
-    "qg_version", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
+    "qg_version", "qg_build_id", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
     "qg_step_device_packed", "qg_get_state", "qg_step_mirror", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_debug_phase_times", "qg_set_task", "qg_get_task",
     "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
@@ -217,6 +229,8 @@ EXPORTS = (
     "qg_walk_default_params", "qg_walk_create", "qg_walk_destroy", "qg_walk_set_commands", "qg_walk_reset", "qg_walk_step",
     "qg_walk_step_device", "qg_walk_get_estimates", "qg_walk_set_command_sampler", "qg_walk_get_commands",
     "qg_po_create", "qg_po_destroy", "qg_po_obs_dim", "qg_po_reset", "qg_po_step", "qg_po_step_device",
+    "qg_walk_state_bytes", "qg_walk_get_state", "qg_walk_set_state", "qg_po_state_bytes", "qg_po_get_state", "qg_po_set_state",
+    "qg_get_reset_streams", "qg_set_reset_streams",
 )
 
 

@@ -71,6 +71,10 @@ int qg_fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *qg_version(void) { return "quadgym 0.1.0 (gfx950)"; }
+#ifndef QG_SOURCE_HASH
+#define QG_SOURCE_HASH "unknown"
+#endif
+extern "C" const char *qg_build_id(void) { return QG_SOURCE_HASH; }
 extern "C" const char *qg_last_error(void) { return g_err; }
 
 extern "C" int qg_default_model(qg_model *out) {

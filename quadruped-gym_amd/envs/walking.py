@@ -125,6 +125,35 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
         check(self._lib.qg_walk_get_commands(self._w, self.velocity.ctypes.data, self.heading.ctypes.data), "qg_walk_get_commands")
         return self.velocity, self.heading
 
+    # -- checkpoint / resume (the reference resumes the policy only, train_quadruped.py:114-141) -------------------
+    def snapshot(self):
+        """Everything this env keeps per robot -- physics state, reset streams, the walking layer's task state (estimator included)
+        and, for the partially observable env, the filter estimate and the frame ring -- as a ``dict`` of NumPy arrays.
+        ``restore(snapshot)`` on an env of the same shape continues bit for bit."""
+        snap = {"sim": self._sim.snapshot()}
+        blob = np.empty(int(self._lib.qg_walk_state_bytes(self._w)), np.uint8)
+        check(self._lib.qg_walk_get_state(self._w, blob.ctypes.data), "qg_walk_get_state")
+        snap["walk"] = blob
+        if getattr(self, "_po", None):
+            pblob = np.empty(int(self._lib.qg_po_state_bytes(self._po)), np.uint8)
+            check(self._lib.qg_po_get_state(self._po, pblob.ctypes.data), "qg_po_get_state")
+            snap["po"] = pblob
+        snap["velocity"], snap["heading"] = self.velocity.copy(), self.heading.copy()
+        return snap
+
+    def restore(self, snap):
+        self._sim.restore(snap["sim"])
+        blob = np.ascontiguousarray(snap["walk"], dtype=np.uint8)
+        if blob.size != int(self._lib.qg_walk_state_bytes(self._w)):
+            raise ValueError("the snapshot was taken from an env of another shape (num_envs / estimator window)")
+        check(self._lib.qg_walk_set_state(self._w, blob.ctypes.data), "qg_walk_set_state")
+        if getattr(self, "_po", None):
+            pblob = np.ascontiguousarray(snap["po"], dtype=np.uint8)
+            if pblob.size != int(self._lib.qg_po_state_bytes(self._po)):
+                raise ValueError("the snapshot was taken from an env of another shape (num_envs / obs_window)")
+            check(self._lib.qg_po_set_state(self._po, pblob.ctypes.data), "qg_po_set_state")
+        self.velocity[:], self.heading[:] = snap["velocity"], snap["heading"]
+
     def _resample(self, idx):
         if self.device_commands:          # already redrawn on the device by the reset / auto-reset itself
             return

@@ -203,7 +203,7 @@ def _load_mjcf(path):
     return roots
 
 
-def compile_mjcf(scene_path, mesh_inertia="convex"):
+def compile_mjcf(scene_path, mesh_inertia="convex", keep_hulls=False):
     """Compile the reference MJCF into the constant tables (a plain dict)."""
     if not os.path.exists(scene_path):
         raise FileNotFoundError(f"Model file not found: {scene_path}")
@@ -310,6 +310,7 @@ def compile_mjcf(scene_path, mesh_inertia="convex"):
 
     # --- body inertials ------------------------------------------------------
     out_bodies = []
+    hull_clouds = []
     for b in bodies:
         mass = 0.0
         first = np.zeros(3)
@@ -337,6 +338,7 @@ def compile_mjcf(scene_path, mesh_inertia="convex"):
             cloud.append(md["hull"] @ quat_to_mat(g["quat"]).T + g["pos"])
         cloud = np.vstack(cloud)
         hv, _ = hull_faces(cloud)
+        hull_clouds.append(cloud[hv])
         if b["parent"] < 0:
             cps = select_contact_points(cloud[hv], CP_FRAME, fold=4)
             # exact 4-fold orbits (3 base points x 4 quarter turns, stored orbit-major): the mesh is symmetric
@@ -400,6 +402,8 @@ def compile_mjcf(scene_path, mesh_inertia="convex"):
         floor_friction=floor_friction,
     )
     _derive_soft_constraints(model)
+    if keep_hulls:          # every vertex of each body's convex hull, body frame (tests: the geometry the sample points were picked from)
+        model["hull_clouds"] = hull_clouds
     return model
 
 

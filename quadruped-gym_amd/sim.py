@@ -181,6 +181,29 @@ class BatchedSim:
                                      nstep.ctypes.data), "qg_get_state")
         return qpos, qvel, act, ctrl, nstep
 
+    def get_reset_streams(self):
+        """``(episode[n] int32, seed)``: the per-env episode counters and the batch seed that key every random draw of a (re)set."""
+        ep = np.empty(self.n, np.int32)
+        seed = C.c_uint64(0)
+        check(self._lib.qg_get_reset_streams(self._h, ep.ctypes.data, C.byref(seed)), "qg_get_reset_streams")
+        return ep, int(seed.value)
+
+    def set_reset_streams(self, episode, seed):
+        ep = np.ascontiguousarray(episode, dtype=np.int32)
+        if ep.shape != (self.n,):
+            raise ValueError(f"expected shape ({self.n},), got {ep.shape}")
+        check(self._lib.qg_set_reset_streams(self._h, ep.ctypes.data, int(seed)), "qg_set_reset_streams")
+
+    def snapshot(self):
+        """Everything the simulator keeps per env: ``dict`` of NumPy arrays (physics state + reset streams)."""
+        qpos, qvel, act, ctrl, nstep = self.get_state()
+        ep, seed = self.get_reset_streams()
+        return {"qpos": qpos, "qvel": qvel, "act": act, "ctrl": ctrl, "nstep": nstep, "episode": ep, "seed": seed}
+
+    def restore(self, snap):
+        self.set_state(snap["qpos"], snap["qvel"], snap["act"], snap["ctrl"], snap["nstep"])
+        self.set_reset_streams(snap["episode"], snap["seed"])
+
     def set_state(self, qpos=None, qvel=None, act=None, ctrl=None, nstep=None):
         def f32(x, w):
             if x is None:

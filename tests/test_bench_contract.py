@@ -70,6 +70,12 @@ def test_bench_prints_one_contract_line_on_one_gpu():
     r = d["roofline"]
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel"] == "qg_step_kernel_link"
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["state_finite"] is True
+    # roofline.traffic / valu_issue / fp32 come from committed counter profiles, not from this run: the line says on which build of the
+    # library they were taken and whether that is the one loaded now (profiles/traffic_index.json is stamped by
+    # tools/update_traffic_index.py with qg_build_id(), a hash of the library's sources)
+    from quadruped_gym_amd import _abi
+    assert r["build_id"] == _abi.load_library().qg_build_id().decode() and len(r["build_id"]) == 16
+    assert r["profile_stale"] == (r["profile_build_id"] != r["build_id"]) and isinstance(r["profile_stale"], bool)
 
 
 @pytest.mark.gpu

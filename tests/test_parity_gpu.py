@@ -620,3 +620,162 @@ def test_register_capped_quad_variants_match_oracle(oracle, wpe, lag):
         _one_step_against_oracle(oracle, 200, 500 + wpe, _abi.MAP_QUAD, sensor_lag=lag)
     finally:
         os.environ.pop("QG_QUAD_WPE", None)
+
+
+def test_host_step_is_ordered_after_a_graph_replay():
+    """Replays of a hipGraph enqueue device-pointer steps the library never sees.  Capture 4 steps on a side stream, do a host step
+    (which takes the device-wide wait and clears the in-flight flag), then replay the graph 40 times (~2 ms of queued kernels at this
+    size) and call the host step at once: it must come AFTER the replays (the handle remembers that it has been captured).  A twin
+    stepped in that order through the host entry point only is the reference -- same kernel, same inputs: bit-identical."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    n, G, R = 32768, 4, 40
+    a, b = BatchedSim(n), BatchedSim(n)
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream(dev)
+    acts_h = np.random.default_rng(5).uniform(-1, 1, (n, 12)).astype(np.float32)
+    acts = torch.from_numpy(acts_h).to(dev)
+    packed = torch.empty((n, 35), device=dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for _ in range(G):
+            a.step_device_packed(acts, packed, stream=torch.cuda.current_stream(dev))
+    a.step(acts_h)                                  # host step: synchronises, the per-launch in-flight flag is clear again
+    b.step(acts_h)
+    with torch.cuda.stream(side):
+        for _ in range(R):
+            graph.replay()
+    obs_a, rew_a, done_a, _ = a.step(acts_h)        # must wait for the 160 replayed steps
+    for _ in range(G * R):
+        b.step(acts_h)
+    obs_b, rew_b, done_b, _ = b.step(acts_h)
+    assert np.array_equal(obs_a, obs_b) and np.array_equal(rew_a, rew_b) and np.array_equal(done_a, done_b)
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
+
+
+def test_link_step_replays_from_a_hipgraph_like_eager():
+    """The plain env-step of the headline mapping (one link per lane, 4096 envs, auto-reset with random yaw) captured into a hipGraph
+    of 8 steps and replayed 20 times leaves the same packed rows and the same state as 160 eager steps of a twin: nothing of the
+    step lives on the host between launches (episode counters and reset streams are device state)."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    n, G, R = 4096, 8, 20
+    task = _abi.default_task()
+    task.auto_reset = 1
+    task.max_time = 0.2                             # 25 env-steps per episode: several auto-resets inside the replays
+    task.reset_flags = _abi.RESET_RANDOM_YAW
+    a, b = BatchedSim(n, task=task), BatchedSim(n, task=task)
+    assert a.mapping == _abi.MAP_LINK
+    a.reset(seed=3, flags=task.reset_flags); b.reset(seed=3, flags=task.reset_flags)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(2)
+    acts = [torch.rand((n, 12), generator=gen, device=dev) * 2 - 1 for _ in range(G)]
+    pa = [torch.empty((n, 35), device=dev) for _ in range(G)]
+    pb = [torch.empty((n, 35), device=dev) for _ in range(G)]
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for g in range(G):
+            a.step_device_packed(acts[g], pa[g], stream=torch.cuda.current_stream(dev))
+    finished = 0
+    for rep in range(R):
+        graph.replay()
+        for g in range(G):
+            b.step_device_packed(acts[g], pb[g])
+        torch.cuda.synchronize()
+        for g in range(G):
+            assert torch.equal(pa[g], pb[g]), (rep, g)
+            finished += int(pa[g][:, 34].sum())
+    assert finished >= 5 * n                        # every env restarted several times inside the graph
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    ea, eb = a.get_reset_streams(), b.get_reset_streams()
+    assert np.array_equal(ea[0], eb[0]) and ea[1] == eb[1] and ea[0].min() >= 5
+    a.close(); b.close()
+
+
+def test_config5_at_full_size_invariants_and_oracle_sample(oracle):
+    """BASELINE config 5 at its size: 4096 envs x frame_skip 20 with the 21-value IMU + joint pack, AUTO = one link per lane.  60
+    env-steps of random actions with the invariants of a healthy batch, then one more step of the whole batch with a strided
+    256-env sample (every lane position of a wave) against the oracle from the same f32 states, within the frame_skip-20 bounds."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n, fs = 4096, 20
+    task = _abi.default_task()
+    task.frame_skip = fs
+    task.obs_mode = 1
+    task.auto_reset = 1
+    task.use_fall = 1
+    task.fall_height = 0.05
+    task.reset_flags = _abi.RESET_RANDOM_YAW
+    sim = BatchedSim(n, task=task)
+    assert sim.mapping == _abi.MAP_LINK and sim.obs_dim == 21
+    sim.reset(seed=11, flags=task.reset_flags)
+    rng = np.random.default_rng(8)
+    for k in range(60):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        obs, rew, done, _ = sim.step(a)
+        assert obs.shape == (n, 21) and np.isfinite(obs).all() and np.isfinite(rew).all()
+    qpos, qvel, act, ctrl, nstep = sim.get_state()
+    assert np.isfinite(qpos).all() and np.isfinite(qvel).all()
+    assert np.allclose(np.linalg.norm(qpos[:, 3:7], axis=1), 1.0, atol=1e-5)
+    assert (np.abs(act) <= 1.0 + 1e-6).all() and (qpos[:, 2] > 0.02).all() and (qpos[:, 2] < 0.3).all()
+    assert (nstep % fs == 0).all() and nstep.max() <= 60 * fs
+    # one more step: the whole batch on the GPU, a strided sample through the oracle from the same f32 states
+    idx = np.arange(0, n, 16) + (np.arange(n // 16) % 16)          # 256 envs, every position within a wave's four envs and beyond
+    a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+    otask = oracle.default_task()
+    otask.frame_skip = fs
+    otask.obs_mode = 1
+    otask.use_fall = 1
+    otask.fall_height = 0.05
+    batch = oracle.Batch(oracle.default_model(), otask, len(idx))
+    batch.reset()
+    batch.set_state(qpos[idx].astype(np.float64), qvel[idx].astype(np.float64), act[idx].astype(np.float64), None, nstep[idx])
+    obs_o, rew_o, done_o, _ = batch.step(a[idx].astype(np.float64))
+    obs, rew, done, _ = sim.step(a)
+    keep = ~(done_o.astype(bool) | np.asarray(done)[idx].astype(bool))          # envs that finished were auto-reset on the GPU
+    assert keep.sum() > 200
+    T = TOL["B"]
+    jp = np.r_[0:12, 15:21]                                         # joint positions, gyro, velocimeter
+    assert np.allclose(obs[idx][keep][:, jp], obs_o[keep][:, jp], atol=T["obs"][0], rtol=T["obs"][1])
+    assert np.allclose(obs[idx][keep][:, 12:15], obs_o[keep][:, 12:15], atol=T["accel"][0], rtol=T["accel"][1])
+    assert np.allclose(rew[idx][keep], rew_o[keep], atol=T["reward"][0], rtol=T["reward"][1])
+    q1 = sim.get_state()[0]
+    assert np.allclose(q1[idx][keep], batch.get_state()[0][keep], atol=T["qpos"][0], rtol=T["qpos"][1])
+    sim.close()
+
+
+def test_standing_height_at_the_joint_centre_command_4096_envs(oracle):
+    """GPU mirror of tests/test_oracle_physics.py::test_standing_height_at_the_joint_centre_command_follows_the_geometry: 4096 robots
+    (AUTO = one link per lane) held at the joint-centre command [0, 0, -0.5] x 4 for 4000 substeps settle where the oracle does --
+    FRAME origin 0.1423 m above the floor, the height the reference's XML + OBJ geometry gives for that pose (not the 0.12 / 0.13 of
+    walking_quad.py:243-247,369) -- hinges at ctrl / gear, every env on the same bits."""
+    from quadruped_gym_amd.sim import BatchedSim
+    n = 4096
+    task = _abi.default_task()
+    task.frame_skip = 20
+    task.use_time_limit = 0
+    sim = BatchedSim(n, task=task)
+    assert sim.mapping == _abi.MAP_LINK
+    sim.reset()
+    a = np.tile(np.array([0, 0, -0.5] * 4, np.float32), (n, 1))
+    for _ in range(200):
+        obs, rew, done, _ = sim.step(a)
+        assert not done.any()
+    qpos, qvel = sim.get_state()[:2]
+    model, otask = oracle.default_model(), oracle.default_task()
+    e = oracle.reset(model, otask)
+    for _ in range(4000):
+        oracle.substep(model, e, np.array(otask.default_ctrl[:]))
+    z_o = e.qpos[2]
+    assert abs(z_o - 0.1423) < 3e-4
+    assert np.abs(qpos[:, 2] - z_o).max() < 2e-4 and np.abs(qvel).max() < 1e-4
+    assert np.allclose(qpos[:, 7:19], np.array(e.qpos[7:19]), atol=2e-4)
+    assert np.allclose(qpos[:, 7:19], [0, 0, -0.78125] * 4, atol=4e-3)           # ctrl / gear
+    assert (qpos == qpos[0]).all()                                                # identical envs, identical bits
+    assert (qpos[:, 2] - 0.13).min() > 0.012
+    sim.close()

@@ -24,8 +24,16 @@ def test_madgwick_restatement_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window,settle", [(1, 0.0), (4, 0.08)])
+@pytest.mark.parametrize("window,settle", [(1, 0.0), (4, 0.08), (10, 0.5)])
 def test_po_frames_match_oracle(window, settle):
+    """The stacked observation against oracle/po_oracle.py at frame_skip 10; (window, settle) = (10, 0.5) is the reference's training
+    setting (src/train_quadruped.py:16-19: obs_window 10, frame_skip 10, settling_time 0.5).
+    What this test does and does not check: the oracle is fed the GPU's OWN frame for the gyro, accelerometer, body-velocity and
+    data.ctrl columns (0-5, 9-10, 11-22 of a frame) -- those are pass-through values here (the physics behind them is checked in
+    tests/test_parity_gpu.py), so for them the comparison only proves that they sit at the right place of the right frame of the
+    stack.  The columns the observation pack COMPUTES are the real checks: the Madgwick-IMU Euler angles (6-8; filter update, the
+    settling-time gate on the f64 clock, the aliasing of the estimate with data.qpos after a reset), the command columns (23-25: the
+    command in force, its heading angle), the FIFO order over `window` frames, and the terminal / reset stacks at auto-resets."""
     from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
     n, fs = 40, 10
     env = POWalkingQuadrupedVecEnv(n, obs_window=window, settling_time=settle, frame_skip=fs, max_time=0.6, random_init=True,

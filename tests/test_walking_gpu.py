@@ -352,3 +352,99 @@ def test_walking_at_config3_size_matches_oracle_on_a_sample():
     assert np.isfinite(env._sim.get_state()[0]).all()
     print(f"largest component difference on the sample: {worst:.2e}")
     env.close()
+
+
+@pytest.mark.parametrize("frame_skip,mapping", [(2, "auto"), (3, "quad"), (1, "pair")])
+def test_estimator_windows_beyond_256_samples_match_oracle(frame_skip, mapping):
+    """math_utils.py:26-28 puts no bound on the estimator window ceil(2 / (min_freq * timestep * frame_skip)): at the shipped 2 ms
+    timestep frame_skip 1 / 2 / 3 give 1000 / 500 / 334 samples (63 / 32 / 21 blocks of 16: more than the 16 block summaries the
+    unrolled rebuild reads).  The estimates over more than one wrap of the ring against the oracle (pinned to the reference's
+    estimator), one fused mapping each."""
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    n = 24
+    env = WalkingQuadrupedVecEnv(n, frame_skip=frame_skip, max_time=1000.0)
+    env._sim.set_mapping({"auto": _abi.MAP_AUTO, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}[mapping])
+    dt = 0.002 * frame_skip
+    o = W.WalkingOracle(n, dt, settling_time=0.0)
+    assert o.est.W == {1: 1000, 2: 500, 3: 334}[frame_skip]
+    env.reset(); o.reset()
+    rng = np.random.default_rng(4)
+    ph = rng.uniform(0, 2 * np.pi, (n, 12)); fr = rng.uniform(0.5, 4.0, (n, 12)); am = rng.uniform(0.1, 1.2, (n, 12))
+    data_ctrl = np.tile([0, 0, -0.5] * 4, (n, 1)).astype(np.float64)
+    steps = o.est.W + o.est.W // 4 + 37
+    checks = 0
+    for k in range(steps):
+        # a slow amplitude envelope makes the window's extrema move from block to block as the ring wraps
+        env_amp = 1.0 + 0.5 * np.sin(2 * np.pi * 0.37 * k * dt)
+        a = (env_amp * am * np.sin(2 * np.pi * fr * k * dt + ph)).astype(np.float32)
+        dones = env.step(a)[2]
+        o.pre_step(np.zeros(n), data_ctrl, a.astype(np.float64))
+        data_ctrl = np.clip(a.astype(np.float64), -1, 1)
+        data_ctrl[dones] = [0, 0, -0.5] * 4               # an env that flipped over was auto-reset: data.ctrl back at its default
+        if k % 61 == 0 or k >= steps - 40:
+            f, amp, _ = env.estimates()
+            assert np.allclose(f, o.f_est, rtol=1e-4, atol=1e-4), (k, np.abs(f - o.f_est).max())
+            assert np.allclose(amp, o.a_est, rtol=1e-4, atol=1e-5), (k, np.abs(amp - o.a_est).max())
+            checks += 1
+    assert checks > 40 and (o.a_est > 0.2).any()
+    env.close()
+
+
+def test_second_walking_layer_on_one_simulator_is_refused():
+    """One task layer per simulator: a second qg_walk_create would save the flags the first one has already switched as the sim's own,
+    and destroying the first would then switch the flip termination and data.ctrl tracking off under the second."""
+    import ctypes as C
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv
+    env = WalkingQuadrupedVecEnv(8)
+    lib = _abi.load_library()
+    h = C.c_void_p()
+    assert lib.qg_walk_create(env._sim._h, None, C.byref(h)) == -1 and not h.value
+    assert b"already bound" in lib.qg_last_error()
+    env.reset()
+    env.step(np.zeros((8, 12), np.float32))                # the bound layer is unharmed
+    env.close()
+
+
+@pytest.mark.parametrize("po,n,mapping", [(False, 300, "auto"), (True, 300, "auto"), (True, 5000, "auto"), (False, 20000, "auto")])
+def test_task_state_snapshot_restores_bit_identical_rollouts(po, n, mapping):
+    """Checkpoint / resume of everything the env keeps per robot: step 300, snapshot, step 50 more (recorded), restore
+    -- into the SAME env and into a freshly built twin -- and step the same 50 again: observations, rewards, dones, components and the
+    final state are identical to the bit.  Auto-resets with random yaw and re-drawn commands happen inside both windows, so the reset
+    streams, the estimator (ring, block summaries, counters) and the frame ring must all have come back."""
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv, WalkingQuadrupedVecEnv
+    kw = dict(settling_time=0.05, frame_skip=4, max_time=0.4, random_init=True, random_controls=True, device_commands=True, seed=13,
+              reset_options={"min_speed": 0.1, "max_speed": 0.4})
+    make = (lambda: POWalkingQuadrupedVecEnv(n, obs_window=5, **kw)) if po else (lambda: WalkingQuadrupedVecEnv(n, **kw))
+    env = make()
+    env.reset()
+    rng = np.random.default_rng(6)
+    acts = [rng.uniform(-1, 1, (n, 12)).astype(np.float32) for _ in range(350)]
+    for k in range(300):
+        env.step(acts[k])
+    snap = env.snapshot()
+
+    def run50(e):
+        out = []
+        for k in range(300, 350):
+            obs, rew, dones, infos = e.step(acts[k])
+            out.append((obs.copy(), rew.copy(), dones.copy(), e.last_components.copy()))
+        return out, e._sim.get_state(), e.commands(), e.estimates()
+    first, st1, cmd1, est1 = run50(env)
+    assert sum(int(d.sum()) for _, _, d, _ in first) > 0            # auto-resets inside the window
+    cmd1 = tuple(x.copy() for x in cmd1)
+    twin = make()
+    twin.reset()
+    for e in (env, twin):
+        e.restore(snap)
+        again, st2, cmd2, est2 = run50(e)
+        for (o1, r1, d1, c1), (o2, r2, d2, c2) in zip(first, again):
+            assert np.array_equal(o1, o2) and np.array_equal(d1, d2)
+            assert np.array_equal(r1, r2, equal_nan=True) and np.array_equal(c1, c2, equal_nan=True)
+        for x, y in zip(st1, st2):
+            assert np.array_equal(x, y)
+        assert all(np.array_equal(x, y) for x, y in zip(cmd1, cmd2)) and all(np.array_equal(x, y) for x, y in zip(est1, est2))
+    # a blob of another shape is refused, not misread
+    other = (POWalkingQuadrupedVecEnv(n + 1, obs_window=5, **kw) if po else WalkingQuadrupedVecEnv(n + 1, **kw))
+    with pytest.raises((ValueError, _abi.QuadGymError)):
+        other.restore(snap)
+    env.close(); twin.close(); other.close()

@@ -5,6 +5,7 @@ set -u
 TAG=${1:-run}; shift || true
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
+(python3 -c "from quadruped_gym_amd import _abi; print(_abi.load_library().qg_build_id().decode())" > $OUT/build_id.txt)
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 /root/repo/bench.py --steps 300 --warmup 30 --no-cpu-baseline --wakeup-ms 0 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 && echo "trace ok"
