@@ -257,6 +257,21 @@ static int effective_mapping(const qg_sim *s) {
     return QG_MAP_QUAD;
 }
 
+// Which step kernels carry the fused observation pack (KPoLaunch): the one-link-per-lane kernel, and -- round 3 -- the four-wave-workgroup
+// forms of the two-legs-per-lane and one-leg-per-lane kernels that AUTO runs above 4096 envs (explicit mapping requests on small
+// grids, which launch the one-wave-workgroup forms, keep the observation pack a launch of its own).
+static bool po_fusable(const qg_sim *s) {
+    const int emap = effective_mapping(s);
+    if (emap == QG_MAP_LINK) return true;
+    if (emap == QG_MAP_PAIR) return (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS > 256;
+    if (emap == QG_MAP_QUAD) {
+        const int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
+        const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
+        return qblocks > 256 && wpe <= 2;
+    }
+    return false;
+}
+
 // `walk` != NULL: the fused walking launch (one-leg-per-lane kernel with the task layer folded in); walk_comps / walk_sample go
 // with it
 // `po` != NULL (with `walk`, one-link-per-lane mapping only): the partially observable observation pack fused in as well
@@ -283,7 +298,7 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
             if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) s->captured_once = 1;
         }
     }
-    if (po && !(walk && emap == QG_MAP_LINK)) return fail(QG_ERR_ARG, "launch_step: the fused observation pack needs the one-link-per-lane walking kernel");
+    if (po && !(walk && po_fusable(s))) return fail(QG_ERR_ARG, "launch_step: no step kernel with the fused observation pack for this handle");
     if (walk && emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
@@ -294,23 +309,29 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         else hipLaunchKernelGGL((qg_step_kernel_link<true, false, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
     } else if (walk && emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
-        if (pblocks > 256)
-            hipLaunchKernelGGL((qg_step_kernel_pair<4, true>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, *walk);
+        if (po)
+            hipLaunchKernelGGL((qg_step_kernel_pair<4, true, true>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, *walk, *po);
+        else if (pblocks > 256)
+            hipLaunchKernelGGL((qg_step_kernel_pair<4, true>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, *walk, KPoNone{});
         else
-            hipLaunchKernelGGL((qg_step_kernel_pair<1, true>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, *walk);
+            hipLaunchKernelGGL((qg_step_kernel_pair<1, true>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, *walk, KPoNone{});
     } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
         const bool wg4 = qblocks > 256;             // four-wave workgroups for grids of more than 256 waves
         dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
-        if (!s->baked) {
-            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk);
-            else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk);
+        if (po) {                                   // po_fusable(): four-wave workgroups, register cap for one or two waves per SIMD
+            if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+            else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+            else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+        } else if (!s->baked) {
+            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else if (wpe == 1) {
-            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk);
-            else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk);
+            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else {
-            hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk);
+            hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         }
     } else if (emap == QG_MAP_LINK) {
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
@@ -321,9 +342,9 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         if (pblocks > 256)
-            hipLaunchKernelGGL((qg_step_kernel_pair<4, false>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, KWalkNone{});
+            hipLaunchKernelGGL((qg_step_kernel_pair<4, false>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, KWalkNone{}, KPoNone{});
         else
-            hipLaunchKernelGGL((qg_step_kernel_pair<1, false>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, KWalkNone{});
+            hipLaunchKernelGGL((qg_step_kernel_pair<1, false>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, KWalkNone{}, KPoNone{});
     } else if (emap == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
         const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
@@ -331,17 +352,17 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
         if (s->baked) {
             const int wpe = s->quad_wpe ? s->quad_wpe : (one_wave ? 1 : 2);
-            if (wpe == 1 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else if (wpe == 2 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            if (wpe == 1 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else if (wpe == 2 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
         } else {
             // tables in LDS: the 256-register cap spills 888 B per lane and measured 2x slower at every grid size (363 vs 741 us
             // at 262 144 envs), so any other robot runs the one-wave-per-SIMD form throughout
-            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
-            else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{});
+            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
         }
     } else if (s->baked)
         hipLaunchKernelGGL(qg_step_kernel<true>, dim3(blocks), dim3(QGK_WAVE), 0, stream, s->d_model, s->d_task, P);
@@ -1173,6 +1194,9 @@ extern "C" int qg_po_create(qg_walk *w, int32_t obs_window, qg_po **out) {
         k.half_settle_substeps = (int32_t)c;
     }
     k.window = obs_window;
+    k.hist_groups = (QG_PO_FRAME * (obs_window - 1) + 3) / 4;        // 16-byte groups per row of history (po_wave_copy_*)
+    k.hg_q64 = k.hist_groups ? 64 / k.hist_groups : 0;
+    k.hg_r64 = k.hist_groups ? 64 % k.hist_groups : 0;
     k.frame_skip = s->task.frame_skip;
     k.auto_reset = s->task.auto_reset;
     for (int i = 0; i < QG_NU; i++) k.default_ctrl[i] = (float)s->task.default_ctrl[i];
@@ -1223,7 +1247,7 @@ extern "C" int qg_po_step_device(qg_po *p, const float *actions, float *obs, flo
     qg_sim *s = w->sim;
     // up to 4096 envs the whole step -- physics, walking task layer, observation pack -- is ONE launch
     // (QG_PO_UNFUSED=1 at qg_create keeps the separate observation-pack launch: the A/B and the parity test of the two forms)
-    if (walk_fused(s) && effective_mapping(s) == QG_MAP_LINK && !s->po_unfused) {
+    if (walk_fused(s) && po_fusable(s) && !s->po_unfused) {
         KPoLaunch pl;
         pl.P = p->kp;
         pl.S = p->st;

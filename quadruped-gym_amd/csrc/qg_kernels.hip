@@ -277,6 +277,7 @@ DEV void wave_sync() {
 }
 
 #include "qg_walk_dev.h"     // walking task layer: per-env device functions used by the fused walking variant of the quad kernel
+#include "qg_po_dev.h"       // partially observable observation pack: per-env / per-wave device functions of the fused <WALK, PO> variants
 
 // start value of hinge j at a reset with QG_RESET_JOINT_JITTER: qpos0 + jitter * U(-1, 1), kept inside the joint range
 DEV float jittered_hinge(float q0, float lo, float hi, float jitter, uint64_t seed, uint64_t env_index, int episode, int j) {
@@ -1104,6 +1105,9 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 }
 
 #define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
+#define QG_PO_COPY_K 4      // 16-byte groups per lane and substep of the fused observation pack's history copy (po_wave_copy_*)
+DEV int PK_window(const KPoLaunch &pk) { return pk.P.window; }
+DEV int PK_window(const KPoNone &) { return 0; }
 
 // WPE = waves per SIMD the register allocation is capped for: 1 (all 512 registers) is fastest while the grid has at
 // most one wave per SIMD (n <= 16384); 2 lets a second wave share the SIMD once the grid is larger.
@@ -1113,9 +1117,14 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 // the episode bookkeeping in the epilogue on the sensor row the wave has just staged in LDS.
 // WAVES: waves per workgroup (1, or 4 = one per SIMD of a CU for grids of more than 256 waves: fewer workgroups to dispatch,
 // see qg_step_kernel_pair); the waves of a workgroup do not interact.
-template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1>
+// PO (with WALK; round 3): the partially observable observation pack fused in as in qg_step_kernel_pair<.., PO> (history copy on the
+// substep loop, frame by the env's lead lane, new frames written by the wave); the register-capped development variants (WPE > 2) have none.
+template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1, bool PO = false>
 __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
-                                                                             const typename WalkArgT<WALK>::type WK) {
+                                                                             const typename WalkArgT<WALK>::type WK,
+                                                                             const typename PoArgT<PO>::type PK) {
+    static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
+    static_assert(!(PO && WPE > 2), "no fused observation pack in the register-capped development variants");
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
     const int lane = threadIdx.x & (QGK_WAVE - 1);
@@ -1220,6 +1229,21 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     int env_e = env, k_e = k;
     int nstep;
     float aclip[3];
+    // PO: the env's filter state and ring position, the rotation of every row of the wave's block into LDS, this lane's first group
+    // of the history copy (see qg_step_kernel_pair)
+    __shared__ int s_off_all[PO ? WAVES : 1][PO ? QGK_QUAD_ENVS : 1];
+    PoEnvIn pin = {};
+    PoCopyState pcs = {0, 0, 0};
+    const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));
+    if constexpr (PO) {
+        if (k == 0) {
+            pin = po_env_load(PK.S, n, env);
+            s_off_all[wave][el] = po_hist_offset(PK.P, pin.head);
+        }
+        po_wave_copy_init(PK.P, lane, live_envs, pcs);
+        wave_sync();
+    }
+    const size_t po_block = PO ? (size_t)(live_envs > 0 ? env0 : 0) * (size_t)(PK_window(PK) * QG_PO_FRAME) : 0;
     if constexpr (!DIET) {
         // Code placement: a wave that is alone on its SIMD is sensitive to where the 14 KB loop body falls relative to the
         // instruction-fetch lines -- the same loop, shifted by one dword through an unrelated edit of the prologue, measured
@@ -1227,8 +1251,18 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         // boundary makes its layout independent of what precedes it.
         QG_MARK(1);                                  // state in registers, prologue stores issued
         asm volatile(".p2align 6");
+        // the history copy's loads at the head of a substep and its stores at the tail -- or both at the head where the registers in
+        // between are taken: with two waves per SIMD the partner covers the latency, and the table-driven variant has none to spare
+        constexpr bool PO_DEFER = PO && WPE == 1 && BAKED;
 #pragma unroll 1
-        for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
+        for (int s = 0; s < fs; ++s) {
+            PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
+            if constexpr (PO) po_wave_copy_load<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, s_off_all[wave], pcs, pcr);
+            if constexpr (PO && !PO_DEFER) po_wave_copy_store<QG_PO_COPY_K>(PK.P, PK.out + po_block, pcs, pcr);
+            substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
+            if constexpr (PO_DEFER) po_wave_copy_store<QG_PO_COPY_K>(PK.P, PK.out + po_block, pcs, pcr);
+        }
+        if constexpr (PO) po_wave_copy_rest<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, PK.out + po_block, s_off_all[wave], pcs);
         QG_MARK(2);                                  // physics done
         if (!lag) {   // un-lagged sensors (task.sensor_lag = 0): one extra forward pass on a scratch copy of the state
             BaseState B2 = B;
@@ -1300,9 +1334,8 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
     wave_sync();                                                   // the tile is this wave's own
-    {
-        const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));      // a whole wave may lie past the last env
-        const int total = live_envs * row;
+    if constexpr (!PO) {
+        const int total = live_envs * row;                               // (a whole wave may lie past the last env: live_envs = 0)
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
         if (row == 35) {                       // rows were staged with a stride of 35 floats: the packed full layout is a straight copy
             for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
@@ -1379,6 +1412,28 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             P.st.act[j * n + env_e] = rst ? 0.f : L.act[i];
             if (P.track_ctrl) P.st.ctrl[j * n + env_e] = rst ? T->default_ctrl[j] : aclip[i];
         }
+    }
+    if constexpr (PO) {
+        __shared__ float s_new_all[WAVES][QGK_QUAD_ENVS][QG_PO_FRAME];     // the frames of this step
+        __shared__ float s_rst_all[WAVES][QGK_QUAD_ENVS][QG_PO_FRAME];     // the frames reset() would return (envs that finished)
+        __shared__ int s_slot_all[WAVES][QGK_QUAD_ENVS], s_fin_all[WAVES][QGK_QUAD_ENVS];
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_new_all[wave][el][11 + 3 * k + i] = aclip[i];            // data.ctrl of the frame
+        }
+        if (lead) {
+            if constexpr (WPE > 1) pin = po_env_load(PK.S, n, env);      // two waves share the SIMD: read again rather than carried through the loop
+            int slot, fin;
+            // an aliasing estimate shows data.qpos[3:7] as the step leaves it: B after the auto-reset above
+            po_frame_env(PK.P, PK.S, n, env, pin, srow, B.qw, B.qx, B.qy, B.qz, win.cvx, win.cvy, win.hx, win.hy, done, s_new_all[wave][el],
+                         s_rst_all[wave][el], slot, fin);
+            s_slot_all[wave][el] = slot;
+            s_fin_all[wave][el] = fin;
+            // random_controls on the device: the new episode's command, drawn only now that both frames show the old one
+            if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
+        }
+        wave_sync();
+        po_wave_emit(PK.P, PK.S, env0, live_envs, lane, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
     }
 }
 
@@ -1504,6 +1559,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
 
 #define QGK_PAIR_ENVS 32    // envs per wave in the two-legs-per-lane kernel
 
+
 // One wave per SIMD by construction (381 registers): capping it to 256 for two resident waves spills 592 B per lane and
 // measured slower than this variant at every size (profiles/r01/pair_sweep.txt), so there is only this one.
 // WAVES: waves per workgroup (1 or 4, one per SIMD of a CU; they do not interact).  A grid of 1024 one-wave workgroups costs ~1.6 us
@@ -1511,9 +1567,15 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
 // one-link-per-lane kernel), so grids of more than 256 waves are launched as four-wave workgroups.
 // WALK: the walking task layer fused in as in qg_step_kernel_quad<.., WALK>; the lane owns the six control channels of its two legs
 // (6 * half .. 6 * half + 5, contiguous in the env-major task state).
-template <int WAVES, bool WALK = false>
+// PO (with WALK; round 3): the partially observable observation pack fused in as well -- POWalkingQuadrupedEnv.step is this one launch
+// also at the batch sizes this kernel serves.  The copy of the W - 1 frames the new stack keeps rides on the substep loop
+// (po_wave_copy_*, qg_po_dev.h: loads at the head of a substep, stores at its tail), the env's lead lane runs the orientation filter
+// on the step's sensors in the epilogue, the wave writes the new frames.  The 33 sensors themselves are not written to memory.
+template <int WAVES, bool WALK = false, bool PO = false>
 __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P,
-                                                                           const typename WalkArgT<WALK>::type WK) {
+                                                                           const typename WalkArgT<WALK>::type WK,
+                                                                           const typename PoArgT<PO>::type PK) {
+    static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
     __shared__ float tile_all[WAVES][QGK_PAIR_ENVS * 35];
     QG_MARK(0);
     const KModel &C = QG_BAKED_MODEL;
@@ -1609,9 +1671,31 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     float zaxis_z = 1.f;
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
+    // PO: the env's filter state and ring position (lead lanes), the rotation of every row of the wave's block into LDS, this
+    // lane's first group of the history copy
+    __shared__ int s_off_all[PO ? WAVES : 1][PO ? QGK_PAIR_ENVS : 1];
+    PoEnvIn pin = {};
+    PoCopyState pcs = {0, 0, 0};
+    const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));
+    if constexpr (PO) {
+        if (half == 0) {
+            pin = po_env_load(PK.S, n, env);
+            s_off_all[wave][el] = po_hist_offset(PK.P, pin.head);
+        }
+        po_wave_copy_init(PK.P, lane, live_envs, pcs);
+        wave_sync();
+    }
+    // (a wave that lies wholly past the last env copies nothing, but its loads are unpredicated: they read block 0)
+    const size_t po_block = PO ? (size_t)(live_envs > 0 ? env0 : 0) * (size_t)(PK_window(PK) * QG_PO_FRAME) : 0;
     QG_MARK(1);                                      // state in registers, prologue stores issued
 #pragma unroll 1
-    for (int s = 0; s < fs; ++s) substep_pair(C, cm, sm, B, L, lag && (s == fs - 1), srow, half, zaxis_z);
+    for (int s = 0; s < fs; ++s) {
+        PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
+        if constexpr (PO) po_wave_copy_load<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, s_off_all[wave], pcs, pcr);
+        substep_pair(C, cm, sm, B, L, lag && (s == fs - 1), srow, half, zaxis_z);
+        if constexpr (PO) po_wave_copy_store<QG_PO_COPY_K>(PK.P, PK.out + po_block, pcs, pcr);
+    }
+    if constexpr (PO) po_wave_copy_rest<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, PK.out + po_block, s_off_all[wave], pcs);
     nstep += fs;
     QG_MARK(2);                                      // physics done
     if (!lag) {
@@ -1639,9 +1723,8 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
     wave_sync();                                                   // the tile is this wave's own
-    {
-        const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));      // a whole wave may lie past the last env
-        const int total = live_envs * row;
+    if constexpr (!PO) {
+        const int total = live_envs * row;                               // (a whole wave may lie past the last env: live_envs = 0)
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
         if (row == 35) {
             for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
@@ -1710,6 +1793,27 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
                 if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[3 * c + i];
             }
         }
+    }
+    if constexpr (PO) {
+        __shared__ float s_new_all[WAVES][QGK_PAIR_ENVS][QG_PO_FRAME];     // the frames of this step
+        __shared__ float s_rst_all[WAVES][QGK_PAIR_ENVS][QG_PO_FRAME];     // the frames reset() would return (envs that finished)
+        __shared__ int s_slot_all[WAVES][QGK_PAIR_ENVS], s_fin_all[WAVES][QGK_PAIR_ENVS];
+        if (live) {
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) s_new_all[wave][el][11 + 6 * half + c6] = aclip[c6];     // data.ctrl of the frame
+        }
+        if (lead) {
+            int slot, fin;
+            // an aliasing estimate shows data.qpos[3:7] as the step leaves it: B after the auto-reset above
+            po_frame_env(PK.P, PK.S, n, env, pin, srow, B.qw, B.qx, B.qy, B.qz, win.cvx, win.cvy, win.hx, win.hy, done, s_new_all[wave][el],
+                         s_rst_all[wave][el], slot, fin);
+            s_slot_all[wave][el] = slot;
+            s_fin_all[wave][el] = fin;
+            // random_controls on the device: the new episode's command, drawn only now that both frames show the old one
+            if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
+        }
+        wave_sync();
+        po_wave_emit(PK.P, PK.S, env0, live_envs, lane, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
     }
 }
 

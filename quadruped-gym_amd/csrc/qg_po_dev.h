@@ -22,6 +22,10 @@ struct KPoParams {
     int32_t frame_skip;
     int32_t auto_reset;
     float default_ctrl[12];
+    // the history copy of the wave-level fused forms (po_wave_copy_*), precomputed on the host: 16-byte groups per row of history
+    // (ceil(26 (window - 1) / 4); 0 for window 1) and 64 divided by it (quotient, remainder): how a lane's next group follows from
+    // its last one without a division
+    int32_t hist_groups, hg_q64, hg_r64;
 };
 
 struct KPoState {
@@ -360,5 +364,129 @@ __device__ __forceinline__ void po_emit_new(const KPoParams &P, const KPoState &
     if (le < envs && s_fin[le]) {
         float *st = S.stack + (size_t)(env0 + le) * width;
         for (int r = l16; r < width; r += 16) st[r] = s_rst[le][r % QG_PO_FRAME];
+    }
+}
+
+
+// ---- the fused form for the step kernels whose WAVE owns a block of consecutive envs (one leg per lane: 16 envs x 4 lanes, two legs
+// per lane: 32 envs x 2 lanes; round 3).  At the batch sizes these kernels serve the observation pack is HBM traffic -- per env and
+// step 936 B of ring read and 1040 B of row written at window 10, 65 MB per launch at 32 768 envs, 15 us as a kernel of its own at
+// the ~4.5 TB/s it reached -- next to a physics launch that leaves the memory system idle.  So the copy ring -> out of the W - 1
+// frames the new stack keeps is spread over the SUBSTEP LOOP: at the head of a substep a lane loads its next K 16-byte groups, at its
+// tail (2 500 instructions later: the latency has long passed) it stores them.  The wave's rows are contiguous in `out` and in the
+// ring (ENVS x width floats); a group is four consecutive floats of one row's history, group g of the block belongs to lane g mod 64,
+// so a wave-instruction moves 1 KB of consecutive addresses (rows permitting).  The ring is rotated by whole frames (26 floats: even,
+// not a multiple of 4), so a group's source is two 8-byte halves, each wrapped on its own; a row's last group is a half when
+// 26 (W - 1) is not a multiple of 4.  What does not fit into frame_skip x K groups is copied after the loop.
+struct PoF2 { float x, y; };
+struct PoF4 { float x, y, z, w; };
+struct PoCopyState { int c, el, left; };          // this lane's next group: column group within the row's history, row, groups left
+template <int K> struct PoCopyRegs { PoF2 a[K], b[K]; };
+
+// rotation offset (floats) of the oldest frame the new stack keeps, for a ring whose NEWEST frame sits in slot `head`
+__device__ __forceinline__ int po_hist_offset(const KPoParams &P, int head) {
+    int slot = head + 1;                           // the slot the new frame will take (the oldest frame's)
+    if (slot >= P.window) slot = 0;
+    int first = slot + 1;                          // the oldest frame that stays
+    if (first >= P.window) first = 0;
+    return first * QG_PO_FRAME;
+}
+__device__ __forceinline__ void po_wave_copy_init(const KPoParams &P, int lane, int live_envs, PoCopyState &st) {
+    const int hq = P.hist_groups;
+    const int total = live_envs * hq;
+    st.left = lane < total ? (total - lane + 63) >> 6 : 0;
+    st.el = hq > 0 ? lane / hq : 0;
+    st.c = lane - st.el * hq;
+}
+__device__ __forceinline__ void po_copy_advance(const KPoParams &P, int &c, int &el) {
+    c += P.hg_r64; el += P.hg_q64;
+    if (c >= P.hist_groups) { c -= P.hist_groups; el += 1; }
+}
+// loads of this lane's next K groups (unpredicated: a lane past its last group repeats group (0, 0) of the block)
+template <int K>
+__device__ __forceinline__ void po_wave_copy_load(const KPoParams &P, const float *__restrict__ ring_block, const int *s_off, const PoCopyState &st,
+                                                  PoCopyRegs<K> &R) {
+    const int width = P.window * QG_PO_FRAME;
+    int c = st.c, el = st.el;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const bool valid = u < st.left;
+        const int ec = valid ? el : 0, cc = valid ? c : 0;
+        const int x = 4 * cc + s_off[ec], y = x + 2;
+        const int xa = x >= width ? x - width : x, yb = y >= width ? y - width : y;
+        const float *rowp = ring_block + (size_t)ec * width;
+        R.a[u] = *reinterpret_cast<const PoF2 *>(rowp + xa);
+        R.b[u] = *reinterpret_cast<const PoF2 *>(rowp + yb);
+        po_copy_advance(P, c, el);
+    }
+}
+template <int K>
+__device__ __forceinline__ void po_wave_copy_store(const KPoParams &P, float *__restrict__ out_block, PoCopyState &st, const PoCopyRegs<K> &R) {
+    const int width = P.window * QG_PO_FRAME, hist = width - QG_PO_FRAME;
+    int c = st.c, el = st.el;
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        if (u < st.left) {
+            float *dst = out_block + (size_t)el * width + 4 * c;
+            if (4 * c + 4 <= hist) {
+                const PoF4 v = {R.a[u].x, R.a[u].y, R.b[u].x, R.b[u].y};
+                *reinterpret_cast<PoF4 *>(dst) = v;
+            } else {
+                *reinterpret_cast<PoF2 *>(dst) = R.a[u];                  // a row's last group when 26 (W - 1) is not a multiple of 4
+            }
+        }
+        po_copy_advance(P, c, el);
+    }
+    st.c = c; st.el = el;
+    st.left = st.left > K ? st.left - K : 0;
+}
+// what the substep loop did not get to (long windows, small frame_skip): the same groups, load -> store
+template <int K>
+__device__ __forceinline__ void po_wave_copy_rest(const KPoParams &P, const float *__restrict__ ring_block, float *__restrict__ out_block,
+                                                  const int *s_off, PoCopyState &st) {
+    while (__any(st.left > 0)) {
+        PoCopyRegs<K> R;
+        po_wave_copy_load<K>(P, ring_block, s_off, st, R);
+        po_wave_copy_store<K>(P, out_block, st, R);
+    }
+}
+// Epilogue of the wave-level fused forms, after every lead lane has built its env's frame (po_frame_env) into s_new / s_rst /
+// s_slot / s_fin and a wave-level fence: the new frames go into the last 26 values of the rows and into their ring slots; an env
+// that finished (rare) hands out the terminal stack, shows the reset stack and restarts its FIFO from the reset frame.  The whole
+// wave works on its block (env0 .. env0 + live_envs).
+__device__ __forceinline__ void po_wave_emit(const KPoParams &P, const KPoState &S, int env0, int live_envs, int lane,
+                                             const float (*s_new)[QG_PO_FRAME], const float (*s_rst)[QG_PO_FRAME], const int *s_slot,
+                                             const int *s_fin, float *__restrict__ out, float *__restrict__ term_out) {
+    const int W = P.window, width = W * QG_PO_FRAME, hist = width - QG_PO_FRAME;
+    const size_t block = (size_t)env0 * width;
+    for (int idx = lane; idx < live_envs * QG_PO_FRAME; idx += 64) {
+        const int el = idx / QG_PO_FRAME, i = idx - el * QG_PO_FRAME;
+        if (!s_fin[el]) {
+            const float x = s_new[el][i];
+            const size_t row = block + (size_t)el * width;
+            out[row + hist + i] = x;
+            S.stack[row + s_slot[el] * QG_PO_FRAME + i] = x;
+        }
+    }
+    unsigned long long fins = __ballot(lane < live_envs && s_fin[lane < live_envs ? lane : 0] != 0);
+    if (fins == 0) return;                                                 // the usual case
+    for (unsigned long long m = fins; m; m &= m - 1) {
+        const int el = __ffsll((long long)m) - 1;
+        const size_t row = block + (size_t)el * width;
+        const int slot = s_slot[el];
+        for (int r = lane; r < width; r += 64) {
+            const int f = r / QG_PO_FRAME, i = r - f * QG_PO_FRAME;
+            int src = slot + 1 + f;                                        // oldest frame first
+            if (src >= W) src -= W;
+            const float x = (f == W - 1) ? s_new[el][i] : S.stack[row + src * QG_PO_FRAME + i];
+            if (term_out) term_out[row + r] = x;
+            out[row + r] = s_rst[el][i];
+        }
+    }
+    wave_sync();                                                           // every read of the old ring contents is done
+    for (unsigned long long m = fins; m; m &= m - 1) {
+        const int el = __ffsll((long long)m) - 1;
+        const size_t row = block + (size_t)el * width;
+        for (int r = lane; r < width; r += 64) S.stack[row + r] = s_rst[el][r % QG_PO_FRAME];
     }
 }

@@ -149,12 +149,18 @@ def test_po_step_tensor_equals_host_step():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("window,modified,n", [(1, False, 40), (4, False, 40), (10, False, 40), (12, False, 40), (64, False, 40), (10, True, 40),
-                                                (10, False, 4096)])
+                                                (10, False, 4096),
+                                                # round 3: the wave-level fused forms above 4096 envs -- one leg per lane with one and two waves
+                                                # per SIMD (8192 / 40 000 envs), two legs per lane (20 000 / 32 768), tables in LDS (5000, modified
+                                                # robot); windows whose history is and is not a multiple of 16 bytes, a ragged last wave
+                                                (4, False, 8192), (10, False, 20000), (10, False, 32768), (12, False, 40000), (10, True, 5000),
+                                                (1, False, 20001), (64, False, 6001), (2, False, 16389)])
 def test_po_fused_launch_equals_separate_launches(window, modified, n, monkeypatch):
-    """Up to 4096 envs the whole partially observable step is ONE launch (physics + walking task layer + observation pack in
-    qg_step_kernel_link<WALK, PO>); QG_PO_UNFUSED=1 at construction keeps the observation pack a launch of its own.  Same
-    arithmetic, same order: physics, rewards, terminations and re-drawn commands must agree to the bit; the frames to the last bits
-    of the filter's Euler angles (the two kernels contract the same expressions into different FMAs)."""
+    """The whole partially observable step is ONE launch at every batch size AUTO serves: physics + walking task layer + observation
+    pack in qg_step_kernel_link<WALK, PO> up to 4096 envs and (round 3) in qg_step_kernel_quad / _pair<.., WALK, PO> above;
+    QG_PO_UNFUSED=1 at construction keeps the observation pack a launch of its own.  Same arithmetic, same order: physics, rewards,
+    terminations and re-drawn commands must agree to the bit; the frames to the last bits of the filter's Euler angles (the kernels
+    contract the same expressions into different FMAs)."""
     from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv
     fs = 4                                                         # n = 40: 2.5 workgroups of the fused kernel; 4096: the full grid
     kw = dict(obs_window=window, settling_time=0.05, frame_skip=fs, max_time=0.12, random_init=True, random_controls=True,
@@ -178,7 +184,7 @@ def test_po_fused_launch_equals_separate_launches(window, modified, n, monkeypat
     assert np.array_equal(fused.reset(), split.reset())
     rng = np.random.default_rng(2)
     finished, worst = 0, 0.0
-    for k in range(50):                                            # 15 env-steps per episode: three auto-resets per env
+    for k in range(50 if n <= 8192 else 34):                       # 15 env-steps per episode: three (two) auto-resets per env
         a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
         o1, r1, d1, i1 = fused.step(a)
         o2, r2, d2, i2 = split.step(a)

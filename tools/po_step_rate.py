@@ -29,7 +29,7 @@ for k in range(steps):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / steps * 1e3
-form = "separate observation-pack launch" if (os.environ.get("QG_PO_UNFUSED") or n > 4096) else "one launch"
+form = "separate observation-pack launch" if os.environ.get("QG_PO_UNFUSED") else "one launch"
 print(f"PO walking step ({form}; frame_skip 10, window {win}), {n} envs: {us:.2f} us per env-step = {n / us:.1f} M env-steps/s; "
       f"finite {bool(torch.isfinite(obs).all())}")
 env.close()
