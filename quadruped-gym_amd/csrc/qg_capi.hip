@@ -1053,7 +1053,7 @@ extern "C" int qg_walk_get_estimates(qg_walk *w, float *f_est, float *a_est, flo
 struct QgBlobHeader { uint32_t magic, version; int32_t n, window; int64_t bytes; };
 #define QG_BLOB_WALK 0x4b4c5751u   /* "QWLK" */
 #define QG_BLOB_PO 0x4f505751u     /* "QWPO" */
-#define QG_BLOB_VERSION 3u
+#define QG_BLOB_VERSION 4u
 struct QgField { void *ptr; size_t bytes; };
 
 static int walk_fields(const qg_walk *w, QgField *f) {
@@ -1194,9 +1194,6 @@ extern "C" int qg_po_create(qg_walk *w, int32_t obs_window, qg_po **out) {
         k.half_settle_substeps = (int32_t)c;
     }
     k.window = obs_window;
-    k.hist_groups = (QG_PO_FRAME * (obs_window - 1) + 3) / 4;        // 16-byte groups per row of history (po_wave_copy_*)
-    k.hg_q64 = k.hist_groups ? 64 / k.hist_groups : 0;
-    k.hg_r64 = k.hist_groups ? 64 % k.hist_groups : 0;
     k.frame_skip = s->task.frame_skip;
     k.auto_reset = s->task.auto_reset;
     for (int i = 0; i < QG_NU; i++) k.default_ctrl[i] = (float)s->task.default_ctrl[i];
@@ -1204,14 +1201,15 @@ extern "C" int qg_po_create(qg_walk *w, int32_t obs_window, qg_po **out) {
     hipError_t e = hipMalloc((void **)&p->st.orient, 4 * n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.alias, n);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.nstep, n * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->st.stack, n * width * 4);
+    // the ring keeps every frame twice (KPoState.stack); 64 bytes of slack: the fused forms' unpredicated 16-byte loads may read past a row
+    if (e == hipSuccess) e = hipMalloc((void **)&p->st.stack, 2 * n * width * 4 + 64);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.head, n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_obs33, n * QG_NSENSOR * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_out, n * width * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_term, n * width * 4);
     if (e == hipSuccess) e = hipMemset(p->st.alias, 0, n);
     if (e == hipSuccess) e = hipMemset(p->st.nstep, 0, n * 4);
-    if (e == hipSuccess) e = hipMemset(p->st.stack, 0, n * width * 4);
+    if (e == hipSuccess) e = hipMemset(p->st.stack, 0, 2 * n * width * 4 + 64);
     if (e == hipSuccess) e = hipMemset(p->st.head, 0, n * 4);
     if (e == hipSuccess) {                                           // computed_orientation = [1, 0, 0, 0] (:19)
         float *h = new float[4 * n];
@@ -1301,7 +1299,7 @@ extern "C" int qg_po_step(qg_po *p, const float *actions, float *obs, float *rew
 
 static int po_fields(const qg_po *p, QgField *f) {
     const size_t n = (size_t)p->walk->sim->n, width = (size_t)p->kp.window * QG_PO_FRAME;
-    const QgField all[] = {{p->st.orient, 4 * n * 4}, {p->st.alias, n}, {p->st.nstep, n * 4}, {p->st.stack, n * width * 4}, {p->st.head, n * 4}};
+    const QgField all[] = {{p->st.orient, 4 * n * 4}, {p->st.alias, n}, {p->st.nstep, n * 4}, {p->st.stack, 2 * n * width * 4}, {p->st.head, n * 4}};
     const int k = (int)(sizeof all / sizeof all[0]);
     if (f) memcpy(f, all, sizeof all);
     return k;

@@ -1105,7 +1105,7 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 }
 
 #define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
-#define QG_PO_COPY_K 4      // 16-byte groups per lane and substep of the fused observation pack's history copy (po_wave_copy_*)
+#define QG_PO_COPY_K 4      // 16-byte groups per lane and substep of the fused observation pack's history copy (po_row_copy_*)
 DEV int PK_window(const KPoLaunch &pk) { return pk.P.window; }
 DEV int PK_window(const KPoNone &) { return 0; }
 
@@ -1199,6 +1199,20 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         L.act[i] = P.st.act[j * n + env];
         sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
     }
+    // PO: the env's filter state (lead lane) and ring position, this lane's share of its env's row copy ring -> out -- its loads go
+    // out here, among the state loads and before the task layer's stores (see qg_step_kernel_pair)
+    PoEnvIn pin = {};
+    PoCopyState pcs = {};
+    const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));
+    const int el_c = min(el, max(live_envs - 1, 0));     // row of this lane's env in the wave's block (tail lanes: the last live one)
+    unsigned long long po_ring = 0, po_out = 0;          // the wave's block of the frame ring / of the output rows (scalar registers)
+    if constexpr (PO) {
+        const size_t po_block = (size_t)(live_envs > 0 ? env0 : 0) * (size_t)(PK.P.window * QG_PO_FRAME);
+        po_ring = po_uniform_addr(PK.S.stack + 2 * po_block);
+        po_out = po_uniform_addr(PK.out + po_block);
+        if (k == 0) pin = po_env_load(PK.S, n, env);
+        po_row_copy_init<4, (WPE == 1 && BAKED)>(PK.P, po_ring, el_c, PK.S.head[env], k, pcs);
+    }
     if constexpr (WALK) {
         // every state value is in its register before the first store of the task layer is issued: the waits for those loads
         // would otherwise sit behind the stores (vmcnt is in order) right in front of the substep loop
@@ -1229,21 +1243,6 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     int env_e = env, k_e = k;
     int nstep;
     float aclip[3];
-    // PO: the env's filter state and ring position, the rotation of every row of the wave's block into LDS, this lane's first group
-    // of the history copy (see qg_step_kernel_pair)
-    __shared__ int s_off_all[PO ? WAVES : 1][PO ? QGK_QUAD_ENVS : 1];
-    PoEnvIn pin = {};
-    PoCopyState pcs = {0, 0, 0};
-    const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));
-    if constexpr (PO) {
-        if (k == 0) {
-            pin = po_env_load(PK.S, n, env);
-            s_off_all[wave][el] = po_hist_offset(PK.P, pin.head);
-        }
-        po_wave_copy_init(PK.P, lane, live_envs, pcs);
-        wave_sync();
-    }
-    const size_t po_block = PO ? (size_t)(live_envs > 0 ? env0 : 0) * (size_t)(PK_window(PK) * QG_PO_FRAME) : 0;
     if constexpr (!DIET) {
         // Code placement: a wave that is alone on its SIMD is sensitive to where the 14 KB loop body falls relative to the
         // instruction-fetch lines -- the same loop, shifted by one dword through an unrelated edit of the prologue, measured
@@ -1257,12 +1256,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
 #pragma unroll 1
         for (int s = 0; s < fs; ++s) {
             PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
-            if constexpr (PO) po_wave_copy_load<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, s_off_all[wave], pcs, pcr);
-            if constexpr (PO && !PO_DEFER) po_wave_copy_store<QG_PO_COPY_K>(PK.P, PK.out + po_block, pcs, pcr);
+            if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 4>(po_ring, pcs, pcr);
+            if constexpr (PO && !PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(po_out, live, pcs, pcr);
             substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
-            if constexpr (PO_DEFER) po_wave_copy_store<QG_PO_COPY_K>(PK.P, PK.out + po_block, pcs, pcr);
+            if constexpr (PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(po_out, live, pcs, pcr);
         }
-        if constexpr (PO) po_wave_copy_rest<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, PK.out + po_block, s_off_all[wave], pcs);
+        if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 4, PO_DEFER>(PK.P, po_ring, po_out, live, el_c, k, pcs);
         QG_MARK(2);                                  // physics done
         if (!lag) {   // un-lagged sensors (task.sensor_lag = 0): one extra forward pass on a scratch copy of the state
             BaseState B2 = B;
@@ -1433,7 +1432,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
         }
         wave_sync();
-        po_wave_emit(PK.P, PK.S, env0, live_envs, lane, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
+        po_wave_emit<4>(PK.P, PK.S, env0, live_envs, lane, el, k, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
     }
 }
 
@@ -1569,7 +1568,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
 // (6 * half .. 6 * half + 5, contiguous in the env-major task state).
 // PO (with WALK; round 3): the partially observable observation pack fused in as well -- POWalkingQuadrupedEnv.step is this one launch
 // also at the batch sizes this kernel serves.  The copy of the W - 1 frames the new stack keeps rides on the substep loop
-// (po_wave_copy_*, qg_po_dev.h: loads at the head of a substep, stores at its tail), the env's lead lane runs the orientation filter
+// (po_row_copy_*, qg_po_dev.h: loads at the head of a substep, stores at its tail), the env's lead lane runs the orientation filter
 // on the step's sensors in the epilogue, the wave writes the new frames.  The 33 sensors themselves are not written to memory.
 template <int WAVES, bool WALK = false, bool PO = false>
 __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const KTask *__restrict__ T, KStepArgs P,
@@ -1656,6 +1655,21 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     ssq = pair_sum(ssq);
 #pragma unroll
     for (int i = 0; i < 3; ++i) sincos_f(L.q[i] - f2(C.link[i].ref), L.sc[2 * i], L.sc[2 * i + 1]);
+    // PO: the env's filter state (lead lane) and ring position, this lane's share of its env's row copy ring -> out -- its loads go
+    // out here, among the state loads and before the task layer's stores
+    PoEnvIn pin = {};
+    PoCopyState pcs = {};
+    const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));
+    const int el_c = min(el, max(live_envs - 1, 0));     // row of this lane's env in the wave's block (tail lanes: the last live one)
+    unsigned long long po_ring = 0, po_out = 0;          // the wave's block of the frame ring / of the output rows (scalar registers)
+    if constexpr (PO) {
+        // (a wave that lies wholly past the last env copies nothing, but its loads are unpredicated: they read block 0)
+        const size_t po_block = (size_t)(live_envs > 0 ? env0 : 0) * (size_t)(PK.P.window * QG_PO_FRAME);
+        po_ring = po_uniform_addr(PK.S.stack + 2 * po_block);
+        po_out = po_uniform_addr(PK.out + po_block);
+        if (half == 0) pin = po_env_load(PK.S, n, env);
+        po_row_copy_init<2, true>(PK.P, po_ring, el_c, PK.S.head[env], half, pcs);
+    }
     if constexpr (WALK) {
         asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
                      "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(L.q[0].x), "v"(L.q[1].x), "v"(L.q[2].x), "v"(L.q[0].y), "v"(L.q[1].y), "v"(L.q[2].y),
@@ -1671,31 +1685,16 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     float zaxis_z = 1.f;
     const int fs = T->frame_skip;
     const bool lag = T->sensor_lag != 0;
-    // PO: the env's filter state and ring position (lead lanes), the rotation of every row of the wave's block into LDS, this
-    // lane's first group of the history copy
-    __shared__ int s_off_all[PO ? WAVES : 1][PO ? QGK_PAIR_ENVS : 1];
-    PoEnvIn pin = {};
-    PoCopyState pcs = {0, 0, 0};
-    const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));
-    if constexpr (PO) {
-        if (half == 0) {
-            pin = po_env_load(PK.S, n, env);
-            s_off_all[wave][el] = po_hist_offset(PK.P, pin.head);
-        }
-        po_wave_copy_init(PK.P, lane, live_envs, pcs);
-        wave_sync();
-    }
-    // (a wave that lies wholly past the last env copies nothing, but its loads are unpredicated: they read block 0)
-    const size_t po_block = PO ? (size_t)(live_envs > 0 ? env0 : 0) * (size_t)(PK_window(PK) * QG_PO_FRAME) : 0;
+    // PO: the env's filter state (lead lane) and ring position, this lane's share of its env's row copy ring -> out
     QG_MARK(1);                                      // state in registers, prologue stores issued
 #pragma unroll 1
     for (int s = 0; s < fs; ++s) {
         PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
-        if constexpr (PO) po_wave_copy_load<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, s_off_all[wave], pcs, pcr);
+        if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 2>(po_ring, pcs, pcr);
         substep_pair(C, cm, sm, B, L, lag && (s == fs - 1), srow, half, zaxis_z);
-        if constexpr (PO) po_wave_copy_store<QG_PO_COPY_K>(PK.P, PK.out + po_block, pcs, pcr);
+        if constexpr (PO) po_row_copy_store<QG_PO_COPY_K, 2>(po_out, live, pcs, pcr);
     }
-    if constexpr (PO) po_wave_copy_rest<QG_PO_COPY_K>(PK.P, PK.S.stack + po_block, PK.out + po_block, s_off_all[wave], pcs);
+    if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 2, true>(PK.P, po_ring, po_out, live, el_c, half, pcs);
     nstep += fs;
     QG_MARK(2);                                      // physics done
     if (!lag) {
@@ -1794,6 +1793,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
             }
         }
     }
+    QG_MARK(6);                                      // reset block, state stores issued
     if constexpr (PO) {
         __shared__ float s_new_all[WAVES][QGK_PAIR_ENVS][QG_PO_FRAME];     // the frames of this step
         __shared__ float s_rst_all[WAVES][QGK_PAIR_ENVS][QG_PO_FRAME];     // the frames reset() would return (envs that finished)
@@ -1813,8 +1813,11 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
             if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
         }
         wave_sync();
-        po_wave_emit(PK.P, PK.S, env0, live_envs, lane, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
+        QG_MARK(7);                                  // frame built
+        po_wave_emit<2>(PK.P, PK.S, env0, live_envs, lane, el, half, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
+        QG_MARK(8);                                  // rows written
     }
+    QG_MARK(9);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -52,10 +52,11 @@ __global__ void qg_po_reset_kernel(KPoParams P, KPoState S, int n, const uint8_t
     rf[6] = roll; rf[7] = pitch; rf[8] = yaw; rf[9] = 0.f; rf[10] = 0.f;
     for (int j = 0; j < 12; ++j) rf[11 + j] = P.default_ctrl[j];
     rf[23] = vel[env]; rf[24] = vel[n + env]; rf[25] = po_atan2(head[n + env], head[env]);
-    float *st = S.stack + (size_t)env * P.window * QG_PO_FRAME;
+    float *st = S.stack + 2 * (size_t)env * P.window * QG_PO_FRAME;       // the ring holds every frame twice (KPoState.stack)
     for (int f = 0; f < P.window; ++f)
         for (int i = 0; i < QG_PO_FRAME; ++i) {
             st[f * QG_PO_FRAME + i] = rf[i];
+            st[(P.window + f) * QG_PO_FRAME + i] = rf[i];
             if (out) out[(size_t)env * P.window * QG_PO_FRAME + f * QG_PO_FRAME + i] = rf[i];
         }
     S.alias[env] = 1;

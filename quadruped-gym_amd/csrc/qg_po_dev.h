@@ -22,17 +22,16 @@ struct KPoParams {
     int32_t frame_skip;
     int32_t auto_reset;
     float default_ctrl[12];
-    // the history copy of the wave-level fused forms (po_wave_copy_*), precomputed on the host: 16-byte groups per row of history
-    // (ceil(26 (window - 1) / 4); 0 for window 1) and 64 divided by it (quotient, remainder): how a lane's next group follows from
-    // its last one without a division
-    int32_t hist_groups, hg_q64, hg_r64;
 };
 
 struct KPoState {
     float *orient;       // [4][n]  computed_orientation
     uint8_t *alias;      // [n]     the estimate is the live data.qpos[3:7]
     int32_t *nstep;      // [n]     substeps since the last reset (data.time of the step being observed)
-    float *stack;        // [n][window][26]  ring of the last `window` frames
+    float *stack;        // [n][2 window][26]  ring of the last `window` frames, kept TWICE: slot s and slot s + window hold the same
+                         // frame, so any `window` consecutive frames -- oldest first, as the observation wants them -- are one
+                         // contiguous run starting at the oldest frame's slot, whatever the ring's rotation (round 3: the fused
+                         // forms copy a row with plain 16-byte loads instead of wrapping every 8 bytes; one more frame written per step)
     int32_t *head;       // [n]              ring slot of the newest frame
 };
 
@@ -203,7 +202,7 @@ __device__ __forceinline__ void po_emit_rows(const KPoParams &P, const KPoState 
         const size_t row = (size_t)(env0 + le) * width;
         float *__restrict__ o = out + row;
         float *__restrict__ t_o = term_out ? term_out + row : nullptr;
-        const float *__restrict__ st = S.stack + row;
+        const float *__restrict__ st = S.stack + 2 * row;                  // the ring's rows are two windows long (second copy behind the first)
         const int slot = s_slot[le];
         const bool fin = s_fin[le] != 0;
         // four segments per trip: the four ring reads are issued before the first store
@@ -231,14 +230,14 @@ __device__ __forceinline__ void po_emit_rows(const KPoParams &P, const KPoState 
             }
         }
         if (!fin) {                                                        // nobody reads the slot of the newest frame above
-            float *ring = S.stack + row + (size_t)slot * QG_PO_FRAME;
-            for (int i = l16; i < QG_PO_FRAME; i += 16) ring[i] = s_new[le][i];
+            float *ring = S.stack + 2 * row + (size_t)slot * QG_PO_FRAME;
+            for (int i = l16; i < QG_PO_FRAME; i += 16) { const float x = s_new[le][i]; ring[i] = x; ring[width + i] = x; }
         }
     }
     __syncthreads();                                                       // every read of the old ring contents is done
     if (le < envs && s_fin[le]) {                                          // restart the FIFO from the reset frame
-        float *st = S.stack + (size_t)(env0 + le) * width;
-        for (int r = l16; r < width; r += 16) st[r] = s_rst[le][r % QG_PO_FRAME];
+        float *st = S.stack + 2 * (size_t)(env0 + le) * width;
+        for (int r = l16; r < 2 * width; r += 16) st[r] = s_rst[le][r % QG_PO_FRAME];
     }
 }
 
@@ -255,7 +254,7 @@ __device__ __forceinline__ void po_copy_history(const KPoParams &P, const KPoSta
     // that owns the env.
     const int W = P.window, width = W * QG_PO_FRAME, hist = width - QG_PO_FRAME;
     const int off = (slot + 1 >= W ? 0 : slot + 1) * QG_PO_FRAME;
-    const float *__restrict__ st = S.stack + row;
+    const float *__restrict__ st = S.stack + 2 * row;                      // rows of the ring are two windows long
     float *__restrict__ o = out + row;
     for (int r0 = l16; r0 < hist; r0 += 256) {
         float v[16];
@@ -340,13 +339,14 @@ __device__ __forceinline__ void po_emit_new(const KPoParams &P, const KPoState &
     if (le < envs) {
         const size_t row = (size_t)(env0 + le) * width;
         float *__restrict__ o = out + row;
-        float *__restrict__ stw = S.stack + row;
+        float *__restrict__ stw = S.stack + 2 * row;                       // rows of the ring are two windows long
         const int slot = s_slot[le];
         if (!s_fin[le]) {
             for (int i = l16; i < QG_PO_FRAME; i += 16) {
                 const float x = s_new[le][i];
                 o[width - QG_PO_FRAME + i] = x;
                 stw[slot * QG_PO_FRAME + i] = x;
+                stw[width + slot * QG_PO_FRAME + i] = x;
             }
         } else {
             float *__restrict__ t_o = term_out ? term_out + row : nullptr;
@@ -362,131 +362,166 @@ __device__ __forceinline__ void po_emit_new(const KPoParams &P, const KPoState &
     }
     wave_sync();                                                           // every read of the old ring contents is done
     if (le < envs && s_fin[le]) {
-        float *st = S.stack + (size_t)(env0 + le) * width;
-        for (int r = l16; r < width; r += 16) st[r] = s_rst[le][r % QG_PO_FRAME];
+        float *st = S.stack + 2 * (size_t)(env0 + le) * width;
+        for (int r = l16; r < 2 * width; r += 16) st[r] = s_rst[le][r % QG_PO_FRAME];
     }
 }
 
 
 // ---- the fused form for the step kernels whose WAVE owns a block of consecutive envs (one leg per lane: 16 envs x 4 lanes, two legs
 // per lane: 32 envs x 2 lanes; round 3).  At the batch sizes these kernels serve the observation pack is HBM traffic -- per env and
-// step 936 B of ring read and 1040 B of row written at window 10, 65 MB per launch at 32 768 envs, 15 us as a kernel of its own at
-// the ~4.5 TB/s it reached -- next to a physics launch that leaves the memory system idle.  So the copy ring -> out of the W - 1
-// frames the new stack keeps is spread over the SUBSTEP LOOP: at the head of a substep a lane loads its next K 16-byte groups, at its
-// tail (2 500 instructions later: the latency has long passed) it stores them.  The wave's rows are contiguous in `out` and in the
-// ring (ENVS x width floats); a group is four consecutive floats of one row's history, group g of the block belongs to lane g mod 64,
-// so a wave-instruction moves 1 KB of consecutive addresses (rows permitting).  The ring is rotated by whole frames (26 floats: even,
-// not a multiple of 4), so a group's source is two 8-byte halves, each wrapped on its own; a row's last group is a half when
-// 26 (W - 1) is not a multiple of 4.  What does not fit into frame_skip x K groups is copied after the loop.
-struct PoF2 { float x, y; };
-struct PoF4 { float x, y, z, w; };
-struct PoCopyState { int c, el, left; };          // this lane's next group: column group within the row's history, row, groups left
-template <int K> struct PoCopyRegs { PoF2 a[K], b[K]; };
+// step ~1 KB of ring read and ~1 KB of row written at window 10, 65 MB per launch at 32 768 envs, 15 us as a kernel of its own at
+// the ~4.5 TB/s it reached -- next to a physics launch that leaves the memory system idle.  So the copy ring -> out is spread over
+// the SUBSTEP LOOP: at the head of a substep a lane loads its next K 16-byte groups, at its tail (2 500 instructions later: the
+// latency has long passed) it stores them.  The LPE lanes of an env copy THEIR env's row, group g of the row going to lane g mod LPE.
+// With the ring kept twice (KPoState.stack) the row of the new stack is ONE contiguous run of the ring, from the oldest frame that
+// stays: source and destination of a lane's groups are a base each plus compile-time offsets, no wrap, no table.  The row is copied
+// WHOLE: its last 26 values receive the frame that is about to be dropped and are overwritten by the new frame in the epilogue (same
+// wave, program order).  What does not fit into frame_skip x K groups per lane is copied after the loop; the one group (and, for
+// odd windows, the 8-byte half) that only some of the env's lanes have is fetched in the prologue and stored with the rest.
+// 8- and 16-byte accesses of the copy: vector types (a struct cannot be assigned across address spaces), declared with the alignment
+// the data really has -- rows are 8-byte aligned within their buffers, the caller's `out` is only promised to be 4-byte aligned
+typedef float PoF2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float PoF4 __attribute__((ext_vector_type(4), aligned(4)));
+// a pointer every lane of the wave agrees on, into scalar registers -- and typed as GLOBAL memory: after the round trip through
+// integers the compiler no longer knows the address space and would fall back to flat_load / flat_store with 64-bit vector addresses;
+// with it, accesses take the form  global_load v, v_offset32, s[base] offset:imm
+typedef const char __attribute__((address_space(1))) *po_gcptr;
+typedef char __attribute__((address_space(1))) *po_gptr;
+typedef const PoF2 __attribute__((address_space(1))) *po_gcf2;
+typedef PoF2 __attribute__((address_space(1))) *po_gf2;
+typedef const PoF4 __attribute__((address_space(1))) *po_gcf4;
+typedef PoF4 __attribute__((address_space(1))) *po_gf4;
+__device__ __forceinline__ int po_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long po_uniform_addr(const void *p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// this lane's part of its env's row: byte offsets of its next group within the wave's block of the ring / of `out`; `left` = groups
+// every lane of the env still has (wave-uniform); xa / xh: the group / half group that only this lane has (fetched in the prologue)
+struct PoCopyState { unsigned src, dst, row_src; int left; PoF4 xa; PoF2 xh; };
+template <int K> struct PoCopyRegs { PoF4 v[K]; };
 
-// rotation offset (floats) of the oldest frame the new stack keeps, for a ring whose NEWEST frame sits in slot `head`
-__device__ __forceinline__ int po_hist_offset(const KPoParams &P, int head) {
+// el: the env's row within the wave's block (the tail lanes of a ragged last wave pass the last live row: they load, never store);
+// head: ring slot of the env's newest frame; j: this lane's index among the env's LPE lanes
+// PREFETCH: fetch the leftovers now (they stay in six registers through the substep loop) -- or in po_row_copy_rest, where a second
+// wave on the SIMD covers the latency and the register-capped kernels have no registers to spare
+template <int LPE, bool PREFETCH>
+__device__ __forceinline__ void po_row_copy_init(const KPoParams &P, unsigned long long ring_block, int el, int head, int j, PoCopyState &st) {
+    const int wbytes = P.window * QG_PO_FRAME * 4;
     int slot = head + 1;                           // the slot the new frame will take (the oldest frame's)
     if (slot >= P.window) slot = 0;
     int first = slot + 1;                          // the oldest frame that stays
     if (first >= P.window) first = 0;
-    return first * QG_PO_FRAME;
-}
-__device__ __forceinline__ void po_wave_copy_init(const KPoParams &P, int lane, int live_envs, PoCopyState &st) {
-    const int hq = P.hist_groups;
-    const int total = live_envs * hq;
-    st.left = lane < total ? (total - lane + 63) >> 6 : 0;
-    st.el = hq > 0 ? lane / hq : 0;
-    st.c = lane - st.el * hq;
-}
-__device__ __forceinline__ void po_copy_advance(const KPoParams &P, int &c, int &el) {
-    c += P.hg_r64; el += P.hg_q64;
-    if (c >= P.hist_groups) { c -= P.hist_groups; el += 1; }
-}
-// loads of this lane's next K groups (unpredicated: a lane past its last group repeats group (0, 0) of the block)
-template <int K>
-__device__ __forceinline__ void po_wave_copy_load(const KPoParams &P, const float *__restrict__ ring_block, const int *s_off, const PoCopyState &st,
-                                                  PoCopyRegs<K> &R) {
-    const int width = P.window * QG_PO_FRAME;
-    int c = st.c, el = st.el;
-#pragma unroll
-    for (int u = 0; u < K; ++u) {
-        const bool valid = u < st.left;
-        const int ec = valid ? el : 0, cc = valid ? c : 0;
-        const int x = 4 * cc + s_off[ec], y = x + 2;
-        const int xa = x >= width ? x - width : x, yb = y >= width ? y - width : y;
-        const float *rowp = ring_block + (size_t)ec * width;
-        R.a[u] = *reinterpret_cast<const PoF2 *>(rowp + xa);
-        R.b[u] = *reinterpret_cast<const PoF2 *>(rowp + yb);
-        po_copy_advance(P, c, el);
+    const unsigned row_src = (unsigned)(el * 2 * wbytes + first * QG_PO_FRAME * 4), row_dst = (unsigned)(el * wbytes);
+    const int groups = wbytes >> 4, even = groups / LPE;                   // 16-byte groups of a row; groups every lane of the env has
+    st.src = row_src + 16u * j;
+    st.dst = row_dst + 16u * j;
+    st.left = P.window > 1 ? po_uniform(even) : 0;
+    // the leftovers: group even * LPE + j where that is still inside the row, then (rows of an odd number of 8-byte pairs) the last pair
+    st.row_src = row_src;
+    if constexpr (PREFETCH) {
+        const po_gcptr base = (po_gcptr)ring_block;
+        const int g = even * LPE + j;
+        st.xa = *(po_gcf4)(base + (row_src + 16u * (unsigned)(g < groups ? g : 0)));
+        st.xh = *(po_gcf2)(base + (row_src + (unsigned)wbytes - 8u));
     }
 }
-template <int K>
-__device__ __forceinline__ void po_wave_copy_store(const KPoParams &P, float *__restrict__ out_block, PoCopyState &st, const PoCopyRegs<K> &R) {
-    const int width = P.window * QG_PO_FRAME, hist = width - QG_PO_FRAME;
-    int c = st.c, el = st.el;
+// loads of this lane's next K groups (unpredicated within a batch: the last batch of a row may read up to K - 1 groups past it, into
+// the ring's second copy, the next row or the allocation's slack -- never stored)
+template <int K, int LPE>
+__device__ __forceinline__ void po_row_copy_load(unsigned long long ring_block, PoCopyState &st, PoCopyRegs<K> &R) {
+    const po_gcptr base = (po_gcptr)ring_block;
+    if (st.left > 0) {                             // wave-uniform: once the row is done the substeps that follow copy nothing
 #pragma unroll
-    for (int u = 0; u < K; ++u) {
-        if (u < st.left) {
-            float *dst = out_block + (size_t)el * width + 4 * c;
-            if (4 * c + 4 <= hist) {
-                const PoF4 v = {R.a[u].x, R.a[u].y, R.b[u].x, R.b[u].y};
-                *reinterpret_cast<PoF4 *>(dst) = v;
-            } else {
-                *reinterpret_cast<PoF2 *>(dst) = R.a[u];                  // a row's last group when 26 (W - 1) is not a multiple of 4
-            }
+        for (int u = 0; u < K; ++u) R.v[u] = *(po_gcf4)(base + (st.src + 16u * LPE * u));
+        st.src += 16u * LPE * K;
+    }
+}
+template <int K, int LPE>
+__device__ __forceinline__ void po_row_copy_store(unsigned long long out_block, bool live, PoCopyState &st, const PoCopyRegs<K> &R) {
+    const po_gptr base = (po_gptr)out_block;
+    if (live) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            if (u < st.left) *(po_gf4)(base + (st.dst + 16u * LPE * u)) = R.v[u];       // wave-uniform condition: a scalar branch
         }
-        po_copy_advance(P, c, el);
     }
-    st.c = c; st.el = el;
+    st.dst += 16u * LPE * K;
     st.left = st.left > K ? st.left - K : 0;
 }
-// what the substep loop did not get to (long windows, small frame_skip): the same groups, load -> store
-template <int K>
-__device__ __forceinline__ void po_wave_copy_rest(const KPoParams &P, const float *__restrict__ ring_block, float *__restrict__ out_block,
-                                                  const int *s_off, PoCopyState &st) {
-    while (__any(st.left > 0)) {
+// what the substep loop did not get to (long windows, small frame_skip): the same groups, load -> store; then the leftovers
+template <int K, int LPE, bool PREFETCH>
+__device__ __forceinline__ void po_row_copy_rest(const KPoParams &P, unsigned long long ring_block, unsigned long long out_block, bool live, int el,
+                                                 int j, PoCopyState &st) {
+    while (st.left > 0) {
         PoCopyRegs<K> R;
-        po_wave_copy_load<K>(P, ring_block, s_off, st, R);
-        po_wave_copy_store<K>(P, out_block, st, R);
+        po_row_copy_load<K, LPE>(ring_block, st, R);
+        po_row_copy_store<K, LPE>(out_block, live, st, R);
+    }
+    if (P.window > 1 && live) {
+        const int wbytes = P.window * QG_PO_FRAME * 4;
+        const po_gptr obase = (po_gptr)out_block;
+        const int groups = wbytes >> 4, even = groups / LPE;
+        const unsigned row_dst = (unsigned)el * (unsigned)wbytes;
+        const int g = even * LPE + j;
+        if constexpr (!PREFETCH) {
+            const po_gcptr base = (po_gcptr)ring_block;
+            st.xa = *(po_gcf4)(base + (st.row_src + 16u * (unsigned)(g < groups ? g : 0)));
+            st.xh = *(po_gcf2)(base + (st.row_src + (unsigned)wbytes - 8u));
+        }
+        if (g < groups) *(po_gf4)(obase + (row_dst + 16u * g)) = st.xa;
+        if ((wbytes & 8) && j == LPE - 1) *(po_gf2)(obase + (row_dst + (unsigned)wbytes - 8u)) = st.xh;
     }
 }
 // Epilogue of the wave-level fused forms, after every lead lane has built its env's frame (po_frame_env) into s_new / s_rst /
-// s_slot / s_fin and a wave-level fence: the new frames go into the last 26 values of the rows and into their ring slots; an env
-// that finished (rare) hands out the terminal stack, shows the reset stack and restarts its FIFO from the reset frame.  The whole
-// wave works on its block (env0 .. env0 + live_envs).
-__device__ __forceinline__ void po_wave_emit(const KPoParams &P, const KPoState &S, int env0, int live_envs, int lane,
+// s_slot / s_fin and a wave-level fence: the new frames go into the last 26 values of the rows and into their ring slots (both
+// copies); an env that finished (rare) hands out the terminal stack, shows the reset stack and restarts its FIFO from the reset
+// frame.  The LPE lanes of an env write their env's frame in 8-byte pieces (the frame is 13 of them); el = this lane's env within
+// the wave, j = its index among the env's lanes.
+template <int LPE>
+__device__ __forceinline__ void po_wave_emit(const KPoParams &P, const KPoState &S, int env0, int live_envs, int lane, int el, int j,
                                              const float (*s_new)[QG_PO_FRAME], const float (*s_rst)[QG_PO_FRAME], const int *s_slot,
                                              const int *s_fin, float *__restrict__ out, float *__restrict__ term_out) {
     const int W = P.window, width = W * QG_PO_FRAME, hist = width - QG_PO_FRAME;
     const size_t block = (size_t)env0 * width;
-    for (int idx = lane; idx < live_envs * QG_PO_FRAME; idx += 64) {
-        const int el = idx / QG_PO_FRAME, i = idx - el * QG_PO_FRAME;
-        if (!s_fin[el]) {
-            const float x = s_new[el][i];
-            const size_t row = block + (size_t)el * width;
-            out[row + hist + i] = x;
-            S.stack[row + s_slot[el] * QG_PO_FRAME + i] = x;
+    if (el < live_envs && !s_fin[el]) {
+        const size_t row = block + (size_t)el * width;
+        float *__restrict__ o = out + row + hist;
+        float *__restrict__ r0 = S.stack + 2 * row + s_slot[el] * QG_PO_FRAME;
+        const float *fr = s_new[el];
+#pragma unroll
+        for (int t = 0; t < (QG_PO_FRAME / 2 + LPE - 1) / LPE; ++t) {
+            const int pr = j + LPE * t;                                    // 8-byte piece of the frame
+            if (pr < QG_PO_FRAME / 2) {
+                PoF2 v;
+                v.x = fr[2 * pr]; v.y = fr[2 * pr + 1];
+                *reinterpret_cast<PoF2 *>(o + 2 * pr) = v;
+                *reinterpret_cast<PoF2 *>(r0 + 2 * pr) = v;
+                *reinterpret_cast<PoF2 *>(r0 + width + 2 * pr) = v;
+            }
         }
     }
     unsigned long long fins = __ballot(lane < live_envs && s_fin[lane < live_envs ? lane : 0] != 0);
     if (fins == 0) return;                                                 // the usual case
     for (unsigned long long m = fins; m; m &= m - 1) {
-        const int el = __ffsll((long long)m) - 1;
-        const size_t row = block + (size_t)el * width;
-        const int slot = s_slot[el];
+        const int fe = __ffsll((long long)m) - 1;
+        const size_t row = block + (size_t)fe * width;
+        const int slot = s_slot[fe];
         for (int r = lane; r < width; r += 64) {
             const int f = r / QG_PO_FRAME, i = r - f * QG_PO_FRAME;
             int src = slot + 1 + f;                                        // oldest frame first
             if (src >= W) src -= W;
-            const float x = (f == W - 1) ? s_new[el][i] : S.stack[row + src * QG_PO_FRAME + i];
+            const float x = (f == W - 1) ? s_new[fe][i] : S.stack[2 * row + src * QG_PO_FRAME + i];
             if (term_out) term_out[row + r] = x;
-            out[row + r] = s_rst[el][i];
+            out[row + r] = s_rst[fe][i];
         }
     }
     wave_sync();                                                           // every read of the old ring contents is done
     for (unsigned long long m = fins; m; m &= m - 1) {
-        const int el = __ffsll((long long)m) - 1;
-        const size_t row = block + (size_t)el * width;
-        for (int r = lane; r < width; r += 64) S.stack[row + r] = s_rst[el][r % QG_PO_FRAME];
+        const int fe = __ffsll((long long)m) - 1;
+        const size_t row = block + (size_t)fe * width;
+        for (int r = lane; r < 2 * width; r += 64) S.stack[2 * row + r] = s_rst[fe][r % QG_PO_FRAME];
     }
 }

@@ -25,18 +25,21 @@ def kernel_lines(path, key):
 
 
 def largest_loop(lines):
+    """The loop (label .. backward branch) with the most floating-point multiply-adds: the substep loop of a step kernel (rare-path
+    loops of the epilogue can span more instructions)."""
     labels = {}
     for i, ln in enumerate(lines):
         m = re.match(r"^(\.LBB\d+_\d+):", ln)
         if m:
             labels[m.group(1)] = i
-    best = None
+    best, best_score = None, -1
     for i, ln in enumerate(lines):
         m = re.match(r"\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", ln) or re.match(r"\s+s_branch\s+(\.LBB\d+_\d+)", ln)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
-            span = (labels[m.group(1)], i)
-            if best is None or span[1] - span[0] > best[1] - best[0]:
-                best = span
+            a = labels[m.group(1)]
+            score = sum(1 for l in lines[a:i + 1] if re.match(r"\s+v_(pk_)?(fma|fmac|mul)_f32", l))
+            if score > best_score:
+                best, best_score = (a, i), score
     return lines[best[0]:best[1] + 1] if best else lines
 
 
