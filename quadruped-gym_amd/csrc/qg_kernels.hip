@@ -1003,7 +1003,7 @@ struct LegState {
 template <bool BAKED, bool LOWREG, bool DIET = false>
 DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
     const float h = C.h;
-    const BaseCtx bc0 = base_prelude(C, B);
+    const BaseCtx bc0 = base_prelude<true>(C, B);
     V3 gb_keep;
     Sym6 Ic;
     SV fc, Fu;
@@ -1042,7 +1042,7 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
     Fu.a = quad_sum(Fu.a); Fu.l = quad_sum(Fu.l);
     float x6[6];
     {
-        const BaseCtx bc = LOWREG ? base_prelude(C, B) : bc0;      // rebuilt (cheap) rather than kept alive across the leg pass
+        const BaseCtx bc = LOWREG ? base_prelude<true>(C, B) : bc0;      // rebuilt (cheap) rather than kept alive across the leg pass
         SV p0;
         Sym6 Ic0;
         frame_body(C, bc, h, p0, Ic0);
@@ -1099,8 +1099,8 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         L.act[i] = fmaf(L.u[i] - L.act[i], link_of<BAKED>(C, k, i).act_decay, L.act[i]);
     }
     {
-        const BaseCtx bc = LOWREG ? base_prelude(C, B) : bc0;
-        base_integrate(bc, h, wdot, acl, B);
+        const BaseCtx bc = LOWREG ? base_prelude<true>(C, B) : bc0;
+        base_integrate<true>(bc, h, wdot, acl, B);
     }
 }
 
@@ -1153,6 +1153,10 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
     B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised (base_prelude<UNIT>)
+        const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
+        B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
+    }
     LegState L;
     const int nstep0 = P.st.nstep[env];
     float aclip0[3];
@@ -1466,7 +1470,7 @@ struct LegPair { f2 q[3], qd[3], act[3], u[3], sc[6]; };   // sc: sin, cos of (q
 
 DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, bool want_sensors, float *__restrict__ row, int half, float &zaxis_z) {
     const float h = C.h;
-    const BaseCtx bc0 = base_prelude(C, B);
+    const BaseCtx bc0 = base_prelude<true>(C, B);
     V3 gb_keep;
     Sym6 Ic;
     SV fc, Fu;
@@ -1494,7 +1498,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
         Sym6T<f2> Ic2, YFt2;
         SVT<f2> fc2, F2[3], Fu2;
         f2 Hd[3], H01, H02, H12, bj[3];
-        leg_pass<f2, true, true, false>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic2, fc2, F2, Hd, H01, H02, H12, bj, L.sc);
+        leg_pass<f2, true, true, false, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic2, fc2, F2, Hd, H01, H02, H12, bj, L.sc);
         leg_eliminate<f2>(F2, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt2, Fu2);
         sub(Ic2, YFt2);                     // the two legs' Schur complements
         Ic = hpsum(Ic2);                    // sum over the two legs of the lane and over the two lanes of the env
@@ -1552,7 +1556,7 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
     }
     {
         const BaseCtx &bc = bc0;
-        base_integrate(bc, h, wdot, acl, B);
+        base_integrate<true>(bc, h, wdot, acl, B);
     }
 }
 
@@ -1586,7 +1590,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     const int env0 = (blockIdx.x * WAVES + wave) * QGK_PAIR_ENVS;
     const int n = P.n;
     const bool live = env0 + el < n;
-    const int env = live ? env0 + el : n - 1;       // tail pairs shadow the last env; their stores are masked
+    int env = live ? env0 + el : n - 1;             // tail pairs shadow the last env; their stores are masked
     // quarter turns of this lane's two legs: (cos, sin)(90 deg * k), k = 2*half and 2*half + 1
     f2 cm, sm;
     cm.x = half ? -1.f : 1.f; cm.y = 0.f;
@@ -1597,6 +1601,10 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
     B.vw = v3<float>(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3<float>(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised (base_prelude<UNIT>)
+        const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
+        B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
+    }
     int nstep = P.st.nstep[env];
     LegPair L;
     float aclip[6];
@@ -1696,6 +1704,10 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     }
     if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 2, true>(PK.P, po_ring, po_out, live, el_c, half, pcs);
     nstep += fs;
+    // the epilogue's store addresses are derived from `env` AFTER the loop: left visible, the compiler computes two dozen 64-bit
+    // addresses before the loop and carries them through it -- ~60 registers of a kernel that already parks values in AGPRs
+    // (tools/asm_liveness.py found the same in the one-leg-per-lane kernel in round 2)
+    asm volatile("" : "+v"(env));
     QG_MARK(2);                                      // physics done
     if (!lag) {
         BaseState B2 = B;
