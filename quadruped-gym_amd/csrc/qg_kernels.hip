@@ -296,7 +296,8 @@ DEV float jittered_hinge(float q0, float lo, float hi, float jitter, uint64_t se
 // Split in two so that the sample points of one body can be shared out over several lanes.
 // ------------------------------------------------------------------------------------------
 template <class T> DEV void contact_point(V3T<T> r, V3T<T> nl, T zb, T &wsum, V3T<T> &s) {
-    T pen = max_(zb - dot(nl, r), T(0.f));
+    // zb - nl . r as three multiply-adds onto zb (round 3: one instruction fewer per sample point than dot + subtract)
+    T pen = max_(fma_(-nl.x, r.x, fma_(-nl.y, r.y, fma_(-nl.z, r.z, zb))), T(0.f));
     wsum += pen;
     s = fma3(pen, r, s);
 }
@@ -694,8 +695,16 @@ DEV void base_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B
     // q <- q * exp(h w): half-angle series (|h w| / 2 stays far below 0.5 rad)
     float hh = 0.5f * h;
     float x2 = hh * hh * dot(B.wb, B.wb);
-    float sc = hh * fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 5040.f, 1.f / 120.f), -1.f / 6.f), 1.f);
-    float cw = fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 720.f, 1.f / 24.f), -0.5f), 1.f);
+    float sc, cw;
+    if constexpr (RSQ) {
+        // (h |w| / 2)^2 stays below 1e-3 for any body rate the divergence guard lets through a step of 2 ms at 30 rad/s; the terms
+        // dropped here are below 2e-8 of the result even at 100 rad/s, and the quaternion is renormalised right below
+        sc = hh * fmaf(x2, fmaf(x2, 1.f / 120.f, -1.f / 6.f), 1.f);
+        cw = fmaf(x2, fmaf(x2, 1.f / 24.f, -0.5f), 1.f);
+    } else {
+        sc = hh * fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 5040.f, 1.f / 120.f), -1.f / 6.f), 1.f);
+        cw = fmaf(x2, fmaf(x2, fmaf(x2, -1.f / 720.f, 1.f / 24.f), -0.5f), 1.f);
+    }
     V3 dv = sc * B.wb;
     float w = c.w, x = c.x, y = c.y, z = c.z;
     float nw = w * cw - x * dv.x - y * dv.y - z * dv.z;
