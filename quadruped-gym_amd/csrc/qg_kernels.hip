@@ -1275,6 +1275,9 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             if constexpr (PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(po_out, live, pcs, pcr);
         }
         if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 4, PO_DEFER>(PK.P, po_ring, po_out, live, el_c, k, pcs);
+        // the epilogue's addresses are derived from (env, leg) AFTER the loop: visible, they are computed before it and carried through
+        // it (see the register-capped variants below; with two waves per SIMD that was 60 bytes of scratch in the walking variant)
+        if constexpr (WPE > 1 || !BAKED) asm volatile("" : "+v"(env_e), "+v"(k_e));
         QG_MARK(2);                                  // physics done
         if (!lag) {   // un-lagged sensors (task.sensor_lag = 0): one extra forward pass on a scratch copy of the state
             BaseState B2 = B;
