@@ -237,21 +237,24 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
     return QG_OK;
 }
 
-// The one-leg-per-lane kernel (16 envs per wave, ~3.5x fewer instructions per wave, no LDS scratch, lower
-// register pressure) measured faster than one env per lane at every batch size from 1 Ki to 256 Ki envs
-// (profiles/r01/sweep.txt), so AUTO picks it.  The compiled-in robot runs the variant with literal constants; any other
-// numbers run the variant that stages the model tables in LDS.
-// Between 16 Ki and 32 Ki envs the quad grid needs a second wave on some SIMDs (31-35 us) while the two-legs-per-lane
-// kernel (packed f32, 32 envs per wave) still fits one wave per SIMD (25.6-28.3 us): AUTO takes it there, for the
-// compiled-in robot.  From 56 Ki envs up (>= 1.75 rounds of one pair wave per SIMD) it is ahead again by 4-11 %
-// (interleaved same-box A/B up to 512 Ki envs); in between (32 Ki < n < 56 Ki) and up to 16 Ki quad is faster
-// (profiles/r01/pair_sweep.txt).
+// AUTO = the measured optimum per batch size (profiles/r03/map_sweep.txt: every mapping around the boundaries on one box, HIP events,
+// microseconds per launch at frame_skip 4):
+//   envs        link     quad     pair
+//   4 096       12.0     18.1              one link per lane: 1024 waves, one per SIMD
+//   5 120       19.2     18.3              a second link wave per SIMD costs more than the quad kernel's idle SIMDs
+//   16 384               19.0     24.2     one quad wave per SIMD
+//   20 000               28.2     24.5     the quad grid needs a second wave on some SIMDs, the pair grid (32 envs per wave) does not
+//   32 768               29.0     25.3
+//   40 000               40.4     46.7     second round of pair waves (one wave per SIMD by construction) against two resident quad waves
+//   57 344               51.9     47.5     from 1.75 rounds of pair waves on, pair is ahead again
+//   262 144             187.7    187.6
+// The one-env-per-lane kernel (66 us at 4096 envs) only runs on request.  The compiled-in robot runs the variants with literal
+// constants; any other numbers run the variants that stage the model tables in LDS (link up to 4096 envs, quad above; no pair form).
 static int effective_mapping(const qg_sim *s) {
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
     if (s->mapping == QG_MAP_PAIR) return s->baked ? QG_MAP_PAIR : QG_MAP_QUAD;
     if (s->mapping == QG_MAP_LINK) return s->task.sensor_lag ? QG_MAP_LINK : QG_MAP_QUAD;
-    // up to 4096 envs (1024 waves of the one-link-per-lane kernel = one per SIMD): 14.1 against 18.2 us per launch at 4096 envs; above,
-    // a second wave per SIMD doubles its time (21.9 us at 5120 envs) and the one-leg-per-lane kernel is ahead (profiles/r02/map_sweep.txt)
+    // up to 4096 envs: 1024 waves of the one-link-per-lane kernel = one per SIMD
     if (s->task.sensor_lag && s->n <= 1024 * QGK_LINK_ENVS) return QG_MAP_LINK;
     if (s->baked && s->n > 1024 * QGK_QUAD_ENVS && (s->n <= 1024 * QGK_PAIR_ENVS || s->n >= 1792 * QGK_PAIR_ENVS)) return QG_MAP_PAIR;
     return QG_MAP_QUAD;
