@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         po_ring = po_uniform_addr(PK.S.stack + 2 * po_block);
         po_out = po_uniform_addr(PK.out + po_block);
         if (k == 0) pin = po_env_load(PK.S, n, env);
-        po_row_copy_init<4, (WPE == 1 && BAKED)>(PK.P, po_ring, el_c, PK.S.head[env], k, pcs);
+        po_row_copy_init<4>(PK.P, el_c, PK.S.head[env], k, pcs);
     }
     if constexpr (WALK) {
         // every state value is in its register before the first store of the task layer is issued: the waits for those loads
@@ -1269,12 +1269,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
 #pragma unroll 1
         for (int s = 0; s < fs; ++s) {
             PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
-            if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 4>(po_ring, pcs, pcr);
-            if constexpr (PO && !PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(po_out, live, pcs, pcr);
+            if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 4>(PK.P, po_ring, k, s == 0, pcs, pcr);
+            if constexpr (PO && !PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(PK.P, po_out, live, k, s == 0, pcs, pcr);
             substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
-            if constexpr (PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(po_out, live, pcs, pcr);
+            if constexpr (PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(PK.P, po_out, live, k, s == 0, pcs, pcr);
         }
-        if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 4, PO_DEFER>(PK.P, po_ring, po_out, live, el_c, k, pcs);
+        if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 4>(PK.P, po_ring, po_out, live, k, pcs);
         // the epilogue's addresses are derived from (env, leg) AFTER the loop: visible, they are computed before it and carried through
         // it (see the register-capped variants below; with two waves per SIMD that was 60 bytes of scratch in the walking variant)
         if constexpr (WPE > 1 || !BAKED) asm volatile("" : "+v"(env_e), "+v"(k_e));
@@ -1688,7 +1688,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         po_ring = po_uniform_addr(PK.S.stack + 2 * po_block);
         po_out = po_uniform_addr(PK.out + po_block);
         if (half == 0) pin = po_env_load(PK.S, n, env);
-        po_row_copy_init<2, true>(PK.P, po_ring, el_c, PK.S.head[env], half, pcs);
+        po_row_copy_init<2>(PK.P, el_c, PK.S.head[env], half, pcs);
     }
     if constexpr (WALK) {
         asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
@@ -1701,6 +1701,14 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         }
     }
 
+    // data.ctrl of this step (quadruped.py:164: the env-clipped action) is known here: it goes out now, behind the loads (the task
+    // layer has read the PREVIOUS one above), instead of among the epilogue's stores -- at 32 768 envs all 1024 waves reach their 12.7 MB
+    // of epilogue stores at the same moment; an env the step resets gets the default there.  (Same-box A/B, round 3: -0.9 % here, but
+    // +0.4 us in the one-link-per-lane kernel at 4096 envs and +0.5 % in the one-leg-per-lane kernel at 16 384: only this kernel has it.)
+    if (live && P.track_ctrl) {
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) P.st.ctrl[(6 * half + c6) * n + env] = aclip[c6];
+    }
     float *srow = tile + el * 35;
     float zaxis_z = 1.f;
     const int fs = T->frame_skip;
@@ -1710,11 +1718,11 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
 #pragma unroll 1
     for (int s = 0; s < fs; ++s) {
         PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
-        if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 2>(po_ring, pcs, pcr);
+        if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 2>(PK.P, po_ring, half, s == 0, pcs, pcr);
         substep_pair(C, cm, sm, B, L, lag && (s == fs - 1), srow, half, zaxis_z);
-        if constexpr (PO) po_row_copy_store<QG_PO_COPY_K, 2>(po_out, live, pcs, pcr);
+        if constexpr (PO) po_row_copy_store<QG_PO_COPY_K, 2>(PK.P, po_out, live, half, s == 0, pcs, pcr);
     }
-    if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 2, true>(PK.P, po_ring, po_out, live, el_c, half, pcs);
+    if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 2>(PK.P, po_ring, po_out, live, half, pcs);
     nstep += fs;
     // the epilogue's store addresses are derived from `env` AFTER the loop: left visible, the compiler computes two dozen 64-bit
     // addresses before the loop and carries them through it -- ~60 registers of a kernel that already parks values in AGPRs
@@ -1813,7 +1821,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
                 P.st.qpos[(7 + j) * n + env] = rst ? C.qpos0[7 + i] : (c == 0 ? L.q[i].x : L.q[i].y);
                 P.st.qvel[(6 + j) * n + env] = rst ? 0.f : (c == 0 ? L.qd[i].x : L.qd[i].y);
                 P.st.act[j * n + env] = rst ? 0.f : (c == 0 ? L.act[i].x : L.act[i].y);
-                if (P.track_ctrl) P.st.ctrl[j * n + env] = rst ? T->default_ctrl[j] : aclip[3 * c + i];
+                if (P.track_ctrl && rst) P.st.ctrl[j * n + env] = T->default_ctrl[j];          // (the step's data.ctrl went out in the prologue)
             }
         }
     }

@@ -378,7 +378,7 @@ __device__ __forceinline__ void po_emit_new(const KPoParams &P, const KPoState &
 // stays: source and destination of a lane's groups are a base each plus compile-time offsets, no wrap, no table.  The row is copied
 // WHOLE: its last 26 values receive the frame that is about to be dropped and are overwritten by the new frame in the epilogue (same
 // wave, program order).  What does not fit into frame_skip x K groups per lane is copied after the loop; the one group (and, for
-// odd windows, the 8-byte half) that only some of the env's lanes have is fetched in the prologue and stored with the rest.
+// odd windows, the 8-byte half) that only some of the env's lanes have travels with the first substep's batch.
 // 8- and 16-byte accesses of the copy: vector types (a struct cannot be assigned across address spaces), declared with the alignment
 // the data really has -- rows are 8-byte aligned within their buffers, the caller's `out` is only promised to be 4-byte aligned
 typedef float PoF2 __attribute__((ext_vector_type(2), aligned(4)));
@@ -399,80 +399,73 @@ __device__ __forceinline__ unsigned long long po_uniform_addr(const void *p) {
     return ((unsigned long long)hi << 32) | lo;
 }
 // this lane's part of its env's row: byte offsets of its next group within the wave's block of the ring / of `out`; `left` = groups
-// every lane of the env still has (wave-uniform); xa / xh: the group / half group that only this lane has (fetched in the prologue)
-struct PoCopyState { unsigned src, dst, row_src; int left; PoF4 xa; PoF2 xh; };
-template <int K> struct PoCopyRegs { PoF4 v[K]; };
+// every lane of the env still has (wave-uniform); row_src / row_dst: the row's start; xa / xh: the leftovers (below)
+struct PoCopyState { unsigned src, dst, row_src, row_dst; int left; };
+template <int K> struct PoCopyRegs { PoF4 v[K]; PoF4 xa; PoF2 xh; };
 
 // el: the env's row within the wave's block (the tail lanes of a ragged last wave pass the last live row: they load, never store);
 // head: ring slot of the env's newest frame; j: this lane's index among the env's LPE lanes
-// PREFETCH: fetch the leftovers now (they stay in six registers through the substep loop) -- or in po_row_copy_rest, where a second
-// wave on the SIMD covers the latency and the register-capped kernels have no registers to spare
-template <int LPE, bool PREFETCH>
-__device__ __forceinline__ void po_row_copy_init(const KPoParams &P, unsigned long long ring_block, int el, int head, int j, PoCopyState &st) {
+template <int LPE>
+__device__ __forceinline__ void po_row_copy_init(const KPoParams &P, int el, int head, int j, PoCopyState &st) {
     const int wbytes = P.window * QG_PO_FRAME * 4;
     int slot = head + 1;                           // the slot the new frame will take (the oldest frame's)
     if (slot >= P.window) slot = 0;
     int first = slot + 1;                          // the oldest frame that stays
     if (first >= P.window) first = 0;
-    const unsigned row_src = (unsigned)(el * 2 * wbytes + first * QG_PO_FRAME * 4), row_dst = (unsigned)(el * wbytes);
-    const int groups = wbytes >> 4, even = groups / LPE;                   // 16-byte groups of a row; groups every lane of the env has
-    st.src = row_src + 16u * j;
-    st.dst = row_dst + 16u * j;
-    st.left = P.window > 1 ? po_uniform(even) : 0;
-    // the leftovers: group even * LPE + j where that is still inside the row, then (rows of an odd number of 8-byte pairs) the last pair
-    st.row_src = row_src;
-    if constexpr (PREFETCH) {
-        const po_gcptr base = (po_gcptr)ring_block;
-        const int g = even * LPE + j;
-        st.xa = *(po_gcf4)(base + (row_src + 16u * (unsigned)(g < groups ? g : 0)));
-        st.xh = *(po_gcf2)(base + (row_src + (unsigned)wbytes - 8u));
-    }
+    st.row_src = (unsigned)(el * 2 * wbytes + first * QG_PO_FRAME * 4);
+    st.row_dst = (unsigned)(el * wbytes);
+    st.src = st.row_src + 16u * j;
+    st.dst = st.row_dst + 16u * j;
+    st.left = P.window > 1 ? po_uniform(((wbytes >> 4) / LPE)) : 0;        // 16-byte groups of a row that every lane of the env has
 }
 // loads of this lane's next K groups (unpredicated within a batch: the last batch of a row may read up to K - 1 groups past it, into
-// the ring's second copy, the next row or the allocation's slack -- never stored)
+// the ring's second copy, the next row or the allocation's slack -- never stored).  `first`: the substep loop's first batch also
+// fetches the LEFTOVERS -- the one group that only some of the env's lanes have (the row's group count is no multiple of LPE) and,
+// for odd windows, the row's last 8 bytes -- so that they too spend a substep in flight instead of a round trip after the loop
+// (fetched in the prologue they cost more: their address depends on the ring position, a load of its own, and what the compiler then
+// parks in AGPRs has to have arrived first: +2.8 us of prologue at 32 768 envs).
 template <int K, int LPE>
-__device__ __forceinline__ void po_row_copy_load(unsigned long long ring_block, PoCopyState &st, PoCopyRegs<K> &R) {
+__device__ __forceinline__ void po_row_copy_load(const KPoParams &P, unsigned long long ring_block, int j, bool first, PoCopyState &st, PoCopyRegs<K> &R) {
     const po_gcptr base = (po_gcptr)ring_block;
     if (st.left > 0) {                             // wave-uniform: once the row is done the substeps that follow copy nothing
 #pragma unroll
         for (int u = 0; u < K; ++u) R.v[u] = *(po_gcf4)(base + (st.src + 16u * LPE * u));
         st.src += 16u * LPE * K;
     }
+    if (first && P.window > 1) {                   // wave-uniform
+        const int wbytes = P.window * QG_PO_FRAME * 4;
+        const int groups = wbytes >> 4, g = (groups / LPE) * LPE + j;
+        R.xa = *(po_gcf4)(base + (st.row_src + 16u * (unsigned)(g < groups ? g : 0)));
+        R.xh = *(po_gcf2)(base + (st.row_src + (unsigned)wbytes - 8u));
+    }
 }
 template <int K, int LPE>
-__device__ __forceinline__ void po_row_copy_store(unsigned long long out_block, bool live, PoCopyState &st, const PoCopyRegs<K> &R) {
+__device__ __forceinline__ void po_row_copy_store(const KPoParams &P, unsigned long long out_block, bool live, int j, bool first, PoCopyState &st,
+                                                  const PoCopyRegs<K> &R) {
     const po_gptr base = (po_gptr)out_block;
     if (live) {
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             if (u < st.left) *(po_gf4)(base + (st.dst + 16u * LPE * u)) = R.v[u];       // wave-uniform condition: a scalar branch
         }
+        if (first && P.window > 1) {
+            const int wbytes = P.window * QG_PO_FRAME * 4;
+            const int groups = wbytes >> 4, g = (groups / LPE) * LPE + j;
+            if (g < groups) *(po_gf4)(base + (st.row_dst + 16u * g)) = R.xa;
+            if ((wbytes & 8) && j == LPE - 1) *(po_gf2)(base + (st.row_dst + (unsigned)wbytes - 8u)) = R.xh;
+        }
     }
     st.dst += 16u * LPE * K;
     st.left = st.left > K ? st.left - K : 0;
 }
-// what the substep loop did not get to (long windows, small frame_skip): the same groups, load -> store; then the leftovers
-template <int K, int LPE, bool PREFETCH>
-__device__ __forceinline__ void po_row_copy_rest(const KPoParams &P, unsigned long long ring_block, unsigned long long out_block, bool live, int el,
-                                                 int j, PoCopyState &st) {
+// what the substep loop did not get to (long windows, small frame_skip): the same groups, load -> store
+template <int K, int LPE>
+__device__ __forceinline__ void po_row_copy_rest(const KPoParams &P, unsigned long long ring_block, unsigned long long out_block, bool live, int j,
+                                                 PoCopyState &st) {
     while (st.left > 0) {
         PoCopyRegs<K> R;
-        po_row_copy_load<K, LPE>(ring_block, st, R);
-        po_row_copy_store<K, LPE>(out_block, live, st, R);
-    }
-    if (P.window > 1 && live) {
-        const int wbytes = P.window * QG_PO_FRAME * 4;
-        const po_gptr obase = (po_gptr)out_block;
-        const int groups = wbytes >> 4, even = groups / LPE;
-        const unsigned row_dst = (unsigned)el * (unsigned)wbytes;
-        const int g = even * LPE + j;
-        if constexpr (!PREFETCH) {
-            const po_gcptr base = (po_gcptr)ring_block;
-            st.xa = *(po_gcf4)(base + (st.row_src + 16u * (unsigned)(g < groups ? g : 0)));
-            st.xh = *(po_gcf2)(base + (st.row_src + (unsigned)wbytes - 8u));
-        }
-        if (g < groups) *(po_gf4)(obase + (row_dst + 16u * g)) = st.xa;
-        if ((wbytes & 8) && j == LPE - 1) *(po_gf2)(obase + (row_dst + (unsigned)wbytes - 8u)) = st.xh;
+        po_row_copy_load<K, LPE>(P, ring_block, j, false, st, R);
+        po_row_copy_store<K, LPE>(P, out_block, live, j, false, st, R);
     }
 }
 // Epilogue of the wave-level fused forms, after every lead lane has built its env's frame (po_frame_env) into s_new / s_rst /
