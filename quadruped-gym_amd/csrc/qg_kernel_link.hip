@@ -248,17 +248,12 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     // ---- z = L^-1 F, row r in lane r: z0 = F0, z1 = F1 - l10 z0, z2 = F2 - l20 z0 - l21 z1 -----------------------------------------------
     float z[6] = {F.a.x, F.a.y, F.a.z, F.l.x, F.l.y, F.l.z};
     {
-        const float c0 = r == 1 ? l10 : (r == 2 ? l20 : 0.f), c1 = r == 2 ? l21 : 0.f;
-        float zb0[6];
+        // (negated coefficients in registers and each broadcast next to the multiply-add that consumes it: v_fmac_f32_dpp)
+        const float nc0 = r == 1 ? -l10 : (r == 2 ? -l20 : 0.f), nc1 = r == 2 ? -l21 : 0.f;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) zb0[i] = leg_bcast0(z[i]);
+        for (int i = 0; i < 6; ++i) z[i] = fmaf(leg_bcast0(z[i]), nc0, z[i]);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) z[i] = fmaf(-c0, zb0[i], z[i]);
-        float zb1[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) zb1[i] = leg_bcast1(z[i]);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) z[i] = fmaf(-c1, zb1[i], z[i]);
+        for (int i = 0; i < 6; ++i) z[i] = fmaf(leg_bcast1(z[i]), nc1, z[i]);
     }
     // ---- this lane's share of the base block: its own link's inertia and force (summed over the env's lanes they are the legs' composite
     // inertias and forces) minus z z^T / d_r;  F u = sum_r z_r y_r / d_r ----

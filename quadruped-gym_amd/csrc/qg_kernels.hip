@@ -989,7 +989,10 @@ template <int CTRL> DEV float dpp_quad(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
 // sum over the 4 lanes of a quad; every lane gets the bitwise identical result ((a+b)+(c+d), commutative)
+// (fp contract off: with the default "fast" contraction a multiply that feeds `x` is folded into the first add -- fma(a, b, dpp(a * b)) --
+// which computes the product twice and leaves the DPP move unfused; see env_sum in qg_kernel_link.hip)
 DEV float quad_sum(float x) {
+#pragma clang fp contract(off)
     x += dpp_quad<0xB1>(x);   // quad_perm [1,0,3,2]
     x += dpp_quad<0x4E>(x);   // quad_perm [2,3,0,1]
     return x;
@@ -1046,9 +1049,6 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
     }
-    quad_sum(Ic);
-    fc.a = quad_sum(fc.a); fc.l = quad_sum(fc.l);
-    Fu.a = quad_sum(Fu.a); Fu.l = quad_sum(Fu.l);
     float x6[6];
     {
         const BaseCtx bc = LOWREG ? base_prelude<true>(C, B) : bc0;      // rebuilt (cheap) rather than kept alive across the leg pass
@@ -1070,6 +1070,11 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
                 }
             }
             wsum = quad_sum(wsum);
+            // the sums over the quad sit right in front of their uses: the compiler fuses a DPP move into the add that consumes it only
+            // when the two end up within a few instructions of each other in one basic block (33 unfused moves per substep otherwise)
+            quad_sum(Ic);
+            fc.a = quad_sum(fc.a); fc.l = quad_sum(fc.l);
+            Fu.a = quad_sum(Fu.a); Fu.l = quad_sum(Fu.l);
             add(Ic0, Ic);
             b.a = v3(0.f, 0.f, 0.f) - Fu.a - p0.a - fc.a;
             b.l = v3(0.f, 0.f, 0.f) - Fu.l - p0.l - fc.l;
@@ -1461,8 +1466,14 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
 // (tools/ubench/valu_rate.hip), so this pays only where a wave has its SIMD to itself anyway -- a lone wave issues at most
 // every ~4.5 cycles, packed or not: grids of 16-32 Ki envs and, by a smaller margin, >= 56 Ki.  Compiled-in robot only.
 // ------------------------------------------------------------------------------------------
-DEV float pair_sum(float x) { return x + dpp_quad<0xB1>(x); }      // quad_perm [1,0,3,2]: the other lane of the pair
-DEV float hsum(f2 v) { return v.x + v.y; }
+DEV float pair_sum(float x) {                                     // quad_perm [1,0,3,2]: the other lane of the pair
+#pragma clang fp contract(off)
+    return x + dpp_quad<0xB1>(x);
+}
+DEV float hsum(f2 v) {
+#pragma clang fp contract(off)
+    return v.x + v.y;
+}
 DEV V3 hsum(V3T<f2> v) { return v3<float>(hsum(v.x), hsum(v.y), hsum(v.z)); }
 DEV V3 pair_sum(V3 a) { return v3<float>(pair_sum(a.x), pair_sum(a.y), pair_sum(a.z)); }
 DEV Sym3 hpsum(const Sym3T<f2> &a) {
@@ -1513,7 +1524,11 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
         leg_pass<f2, true, true, false, true>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic2, fc2, F2, Hd, H01, H02, H12, bj, L.sc);
         leg_eliminate<f2>(F2, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt2, Fu2);
         sub(Ic2, YFt2);                     // the two legs' Schur complements
-        Ic = hpsum(Ic2);                    // sum over the two legs of the lane and over the two lanes of the env
+        // Sum over the two legs of the lane and over the two lanes of the env, HERE, far from the uses: the DPP moves then stay unfused
+        // (33 v_mov_b32_dpp per substep: the compiler fuses a move into its add only when the two are close, see substep_quad), but
+        // with the sums right in front of the 6x6 solve the lone wave of this kernel ran 2.6 % slower at 32 768 and at 262 144 envs
+        // (same-box A/B, round 3: 25.0 -> 25.65 us; the dependent chain sum -> assemble -> solve has nothing to overlap with there)
+        Ic = hpsum(Ic2);
         fc = hpsum(fc2);
         Fu = hpsum(Fu2);
     }

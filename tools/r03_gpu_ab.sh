@@ -1,5 +1,7 @@
 #!/bin/bash
 cd /root/repo
-tools/abn_libs.sh "tools/lib_base.so tools/lib_ctrlpro.so" "4096" 4
-tools/abn_libs.sh "tools/lib_base.so tools/lib_ctrlpro.so" "32768" 3 --random-yaw
-tools/abn_libs.sh "tools/lib_base.so tools/lib_ctrlpro.so" "16384" 2
+A=${1:-tools/lib_base.so}; B=${2:-tools/lib_new.so}
+tools/abn_libs.sh "$A $B" "32768" 4 --random-yaw
+tools/abn_libs.sh "$A $B" "16384" 3
+tools/abn_libs.sh "$A $B" "49152 262144" 2 --random-yaw
+tools/abn_libs.sh "$A $B" "4096" 2
