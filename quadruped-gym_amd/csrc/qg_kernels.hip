@@ -1120,8 +1120,39 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 
 #define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
 #define QG_PO_COPY_K 4      // 16-byte groups per lane and substep of the fused observation pack's history copy (po_row_copy_*)
-DEV int PK_window(const KPoLaunch &pk) { return pk.P.window; }
-DEV int PK_window(const KPoNone &) { return 0; }
+// Epilogue of the observation pack fused into a kernel whose wave owns ENVS consecutive envs with LPE lanes each (a lane owns NCH =
+// 12 / LPE control channels, `aclip` = this step's env-clipped actions of those): the lanes put data.ctrl into the frame, the env's lead
+// lane runs the orientation filter on the sensor row `srow` the wave has staged in LDS and builds the frame (po_frame_env: the
+// stand-alone kernel's function), then the wave writes the rows (po_wave_emit).  `q` = data.qpos[3:7] as the step leaves it (after an
+// auto-reset: the reset pose), what an aliasing estimate shows; RELOAD: the filter state is read here rather than carried through
+// the substep loop (two waves per SIMD: the partner covers the latency).
+template <int ENVS, int LPE, int WAVES, bool RELOAD>
+DEV void po_wave_epilogue(const KPoLaunch &PK, const KWalkLaunch &WK, const KStepArgs &P, int n, int env, int env0, int live_envs, int wave, int lane,
+                          int el, int j, bool live, bool lead, PoEnvIn pin, const float *srow, const BaseState &B, const WalkEnvIn &win, bool done,
+                          const float *aclip) {
+    constexpr int NCH = 12 / LPE;
+    __shared__ float s_new_all[WAVES][ENVS][QG_PO_FRAME];     // the frames of this step
+    __shared__ float s_rst_all[WAVES][ENVS][QG_PO_FRAME];     // the frames reset() would return (envs that finished)
+    __shared__ int s_slot_all[WAVES][ENVS], s_fin_all[WAVES][ENVS];
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) s_new_all[wave][el][11 + NCH * j + c] = aclip[c];            // data.ctrl of the frame
+    }
+    if (lead) {
+        if constexpr (RELOAD) pin = po_env_load(PK.S, n, env);
+        int slot, fin;
+        po_frame_env(PK.P, PK.S, n, env, pin, srow, B.qw, B.qx, B.qy, B.qz, win.cvx, win.cvy, win.hx, win.hy, done, s_new_all[wave][el],
+                     s_rst_all[wave][el], slot, fin);
+        s_slot_all[wave][el] = slot;
+        s_fin_all[wave][el] = fin;
+        // random_controls on the device: the new episode's command, drawn only now that both frames show the old one
+        if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
+    }
+    wave_sync();
+    QG_MARK(7);                                      // frame built
+    po_wave_emit<LPE>(PK.P, PK.S, env0, live_envs, lane, el, j, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
+    QG_MARK(8);                                      // rows written
+}
 
 // WPE = waves per SIMD the register allocation is capped for: 1 (all 512 registers) is fastest while the grid has at
 // most one wave per SIMD (n <= 16384); 2 lets a second wave share the SIMD once the grid is larger.
@@ -1433,28 +1464,8 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
             if (P.track_ctrl) P.st.ctrl[j * n + env_e] = rst ? T->default_ctrl[j] : aclip[i];
         }
     }
-    if constexpr (PO) {
-        __shared__ float s_new_all[WAVES][QGK_QUAD_ENVS][QG_PO_FRAME];     // the frames of this step
-        __shared__ float s_rst_all[WAVES][QGK_QUAD_ENVS][QG_PO_FRAME];     // the frames reset() would return (envs that finished)
-        __shared__ int s_slot_all[WAVES][QGK_QUAD_ENVS], s_fin_all[WAVES][QGK_QUAD_ENVS];
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) s_new_all[wave][el][11 + 3 * k + i] = aclip[i];            // data.ctrl of the frame
-        }
-        if (lead) {
-            if constexpr (WPE > 1) pin = po_env_load(PK.S, n, env);      // two waves share the SIMD: read again rather than carried through the loop
-            int slot, fin;
-            // an aliasing estimate shows data.qpos[3:7] as the step leaves it: B after the auto-reset above
-            po_frame_env(PK.P, PK.S, n, env, pin, srow, B.qw, B.qx, B.qy, B.qz, win.cvx, win.cvy, win.hx, win.hy, done, s_new_all[wave][el],
-                         s_rst_all[wave][el], slot, fin);
-            s_slot_all[wave][el] = slot;
-            s_fin_all[wave][el] = fin;
-            // random_controls on the device: the new episode's command, drawn only now that both frames show the old one
-            if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
-        }
-        wave_sync();
-        po_wave_emit<4>(PK.P, PK.S, env0, live_envs, lane, el, k, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
-    }
+    if constexpr (PO)
+        po_wave_epilogue<QGK_QUAD_ENVS, 4, WAVES, (WPE > 1)>(PK, WK, P, n, env, env0, live_envs, wave, lane, el, k, live, lead, pin, srow, B, win, done, aclip);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1841,29 +1852,8 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         }
     }
     QG_MARK(6);                                      // reset block, state stores issued
-    if constexpr (PO) {
-        __shared__ float s_new_all[WAVES][QGK_PAIR_ENVS][QG_PO_FRAME];     // the frames of this step
-        __shared__ float s_rst_all[WAVES][QGK_PAIR_ENVS][QG_PO_FRAME];     // the frames reset() would return (envs that finished)
-        __shared__ int s_slot_all[WAVES][QGK_PAIR_ENVS], s_fin_all[WAVES][QGK_PAIR_ENVS];
-        if (live) {
-#pragma unroll
-            for (int c6 = 0; c6 < 6; ++c6) s_new_all[wave][el][11 + 6 * half + c6] = aclip[c6];     // data.ctrl of the frame
-        }
-        if (lead) {
-            int slot, fin;
-            // an aliasing estimate shows data.qpos[3:7] as the step leaves it: B after the auto-reset above
-            po_frame_env(PK.P, PK.S, n, env, pin, srow, B.qw, B.qx, B.qy, B.qz, win.cvx, win.cvy, win.hx, win.hy, done, s_new_all[wave][el],
-                         s_rst_all[wave][el], slot, fin);
-            s_slot_all[wave][el] = slot;
-            s_fin_all[wave][el] = fin;
-            // random_controls on the device: the new episode's command, drawn only now that both frames show the old one
-            if (fin && PK.sample) walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
-        }
-        wave_sync();
-        QG_MARK(7);                                  // frame built
-        po_wave_emit<2>(PK.P, PK.S, env0, live_envs, lane, el, half, s_new_all[wave], s_rst_all[wave], s_slot_all[wave], s_fin_all[wave], PK.out, PK.term_out);
-        QG_MARK(8);                                  // rows written
-    }
+    if constexpr (PO)
+        po_wave_epilogue<QGK_PAIR_ENVS, 2, WAVES, false>(PK, WK, P, n, env, env0, live_envs, wave, lane, el, half, live, lead, pin, srow, B, win, done, aclip);
     QG_MARK(9);
 }
 
