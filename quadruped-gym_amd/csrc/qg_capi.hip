@@ -781,7 +781,7 @@ extern "C" int qg_walk_destroy(qg_walk *w) {
         if (build_tables(&s->model, &s->task, &km, &kt) == QG_OK) (void)hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice);
     }
     void *ptrs[] = {w->st.vel, w->st.head, w->st.gvel, w->st.ideal, w->st.prev_ctrl, w->st.prev_ctrl_cost, w->st.has_ctrl_cost,
-                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.smax, w->st.smin, w->st.omax, w->st.omin, w->st.cross, w->st.count, w->st.prev, w->st.sign,
+                    w->st.prev_derive, w->st.has_derive, w->st.calls, w->st.sig, w->st.bmax, w->st.bmin, w->st.smax, w->st.smin, w->st.cross, w->st.count,
                     w->st.f_est, w->st.a_est, w->st.eff_actions, w->d_obs, w->d_reward, w->d_comps, w->d_actions, w->d_tmp, w->d_done};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -850,10 +850,10 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
         const size_t nbs = nb > QG_WALK_MAXBLOCKS ? nb : QG_WALK_MAXBLOCKS;     // at least the 16 slots the unrolled rebuild reads
         w->ring_slots = Wp; w->summary_blocks = nbs;
         WALLOC(w->st.bmax, nbs * 12 * n * 4); WALLOC(w->st.bmin, nbs * 12 * n * 4);
-        WALLOC(w->st.smax, (size_t)QG_WALK_BLOCK * 12 * n * 4); WALLOC(w->st.smin, (size_t)QG_WALK_BLOCK * 12 * n * 4);
+        WALLOC(w->st.smax, (size_t)(QG_WALK_BLOCK + 1) * 12 * n * 4); WALLOC(w->st.smin, (size_t)(QG_WALK_BLOCK + 1) * 12 * n * 4);
     }
-    WALLOC(w->st.omax, 12 * n * 4); WALLOC(w->st.omin, 12 * n * 4); WALLOC(w->st.count, 12 * n * 4);
-    WALLOC(w->st.prev, 12 * n * 4); WALLOC(w->st.sign, 12 * n * 4); WALLOC(w->st.f_est, 12 * n * 4); WALLOC(w->st.a_est, 12 * n * 4);
+    WALLOC(w->st.count, 12 * n * 4);
+    WALLOC(w->st.f_est, 12 * n * 4); WALLOC(w->st.a_est, 12 * n * 4);
     WALLOC(w->st.eff_actions, 12 * n * 4);
     WALLOC(w->d_obs, n * QG_NSENSOR * 4); WALLOC(w->d_reward, n * 4); WALLOC(w->d_comps, n * QG_NWALKREWARD * 4);
     WALLOC(w->d_actions, n * 12 * 4); WALLOC(w->d_tmp, n * 12 * 4); WALLOC(w->d_done, n);
@@ -1056,7 +1056,7 @@ extern "C" int qg_walk_get_estimates(qg_walk *w, float *f_est, float *a_est, flo
 struct QgBlobHeader { uint32_t magic, version; int32_t n, window; int64_t bytes; };
 #define QG_BLOB_WALK 0x4b4c5751u   /* "QWLK" */
 #define QG_BLOB_PO 0x4f505751u     /* "QWPO" */
-#define QG_BLOB_VERSION 4u
+#define QG_BLOB_VERSION 5u
 struct QgField { void *ptr; size_t bytes; };
 
 static int walk_fields(const qg_walk *w, QgField *f) {
@@ -1065,8 +1065,8 @@ static int walk_fields(const qg_walk *w, QgField *f) {
     const QgField all[] = {
         {S.vel, 2 * n * 4}, {S.head, 2 * n * 4}, {S.gvel, 2 * n * 4}, {S.ideal, 2 * n * 4}, {S.prev_ctrl, 12 * n * 4}, {S.prev_ctrl_cost, n * 4},
         {S.has_ctrl_cost, n}, {S.prev_derive, n * 4}, {S.has_derive, n}, {S.calls, n * 4}, {S.sig, R * 12 * n * 4}, {S.cross, R * 12 * n},
-        {S.bmax, NB * 12 * n * 4}, {S.bmin, NB * 12 * n * 4}, {S.smax, (size_t)QG_WALK_BLOCK * 12 * n * 4}, {S.smin, (size_t)QG_WALK_BLOCK * 12 * n * 4},
-        {S.omax, 12 * n * 4}, {S.omin, 12 * n * 4}, {S.count, 12 * n * 4}, {S.prev, 12 * n * 4}, {S.sign, 12 * n * 4}, {S.f_est, 12 * n * 4},
+        {S.bmax, NB * 12 * n * 4}, {S.bmin, NB * 12 * n * 4}, {S.smax, (size_t)(QG_WALK_BLOCK + 1) * 12 * n * 4}, {S.smin, (size_t)(QG_WALK_BLOCK + 1) * 12 * n * 4},
+        {S.count, 12 * n * 4}, {S.f_est, 12 * n * 4},
         {S.a_est, 12 * n * 4}, {S.eff_actions, 12 * n * 4}};
     const int k = (int)(sizeof all / sizeof all[0]);
     if (f) memcpy(f, all, sizeof all);

@@ -46,14 +46,13 @@ struct KWalkState {
     uint8_t *has_derive;     // [n]      cleared by every reset (:109)
     // estimator (math_utils.py): never reset between episodes (walking_quad.py:115)
     int32_t *calls;          // [n]      update() calls so far: buffer index = calls % window, samples = min(calls, window)
-    float *sig;              // [window][n][12]
+    float *sig;              // [window][n][12]  (the previous sample = the slot before the write index: no copy of it is kept)
     float *bmax, *bmin;      // [blocks][n][12]  max / min of the samples written into each 16-sample block during its latest pass
-    float *omax, *omin;      // [n][12]  max / min over the filled blocks other than the one being written (cache, see walk_estimator_load_n)
-    float *smax, *smin;      // [16][n][12]  suffix max / min of the OLD samples of the block being written: [j] covers old[j .. 15]
+    float *smax, *smin;      // [17][n][12]  extrema of everything in the window EXCEPT what has been written into the block being
+                             //          written during its current pass: [j] = old samples j .. 15 of that block and every other
+                             //          block (j = 1 .. 15; [16] = the other blocks alone); rebuilt when the write index enters a block
     uint8_t *cross;          // [window][n][12]
-    int32_t *count;          // [n][12]  running number of derivative sign changes inside the window
-    float *prev;             // [n][12]
-    float *sign;             // [n][12]  -1 / 0 / +1
+    int32_t *count;          // [n][12]  4 * (running number of derivative sign changes inside the window) + (last derivative sign + 1)
     float *f_est, *a_est;    // [n][12]
     float *eff_actions;      // [n][12]  the action actually applied (joint centres while settling)
 };
@@ -81,12 +80,15 @@ template <> struct WalkArgT<true> { typedef KWalkLaunch type; };
 // levels keep a call's traffic at twelve values per channel:
 //   * the ring is cut into blocks of 16 samples; bmax / bmin[b] hold the extrema of the samples written into block b during its
 //     latest pass (a running value while the write index is inside b, the block's summary once it has moved on);
-//   * omax / omin cache the extrema over all OTHER filled blocks: they only change when the write index enters a new block (every
-//     16th call), where they are rebuilt from the summaries;
+//   * the extrema over all OTHER filled blocks only change when the write index enters a new block (every 16th call), where they
+//     are rebuilt from the summaries;
 //   * what is left of the block being overwritten -- the OLD samples behind the write index, the oldest of the window -- enters
-//     through suffix extrema smax / smin[j] = extrema of old[j .. 15], computed once, when the index enters the block (third pass of
-//     round 2; before, every call re-read the block's 16 samples: 24 values per channel and call, ~1.7 KB of task state traffic per
-//     env-step, which is what bounds the walking step at large batches -- 13 us of HBM-bound prologue at 32 768 envs).
+//     through suffix extrema of old[j .. 15], computed once, when the index enters the block (third pass of round 2; before, every
+//     call re-read the block's 16 samples: 24 values per channel and call);
+//   * round 3: the two are kept TOGETHER -- smax / smin[j] = extrema of (old[j .. 15] and the other blocks), [16] = the other blocks
+//     alone -- the derivative sign rides in the low bits of the sign-change count, and the previous sample is read from the ring
+//     itself: 33 bytes loaded and 25 stored per channel and call instead of 45 and 33.  At large batches the walking prologue is HBM
+//     traffic (~1 KB of task state per env-step against 0.6 KB for the physics: 6.6 us of a 33 us step at 32 768 envs), so bytes are time.
 // Written in three phases -- every load, then the arithmetic, then every store -- so that the loads of all channels are in flight
 // together: inside the fused step kernel a wave is alone on its SIMD and a chain of dependent loads costs its full latency each time
 // (measured: the loop form made the fused walking step 42 us, slower than three launches).
@@ -136,10 +138,10 @@ template <int NCH> __device__ __forceinline__ void walk_stv(int *p, const int (&
 #define QG_WALK_EMPTY_MAX (-3.0e38f)      // "nothing there" (finite: the device pass is compiled with -ffinite-math-only)
 #define QG_WALK_EMPTY_MIN (3.0e38f)
 template <int NCH> struct WalkEstIn {
-    float prev[NCH], psign[NCH], fe[NCH], ae[NCH], om[NCH], on[NCH];
+    float prev[NCH], fe[NCH], ae[NCH];
     float bm[NCH], bn[NCH];               // extrema of the samples written into the current block so far (valid when j0 > 0)
-    float sh[NCH], sl[NCH];               // extrema of the old samples still standing behind the write index (EMPTY if none)
-    int cnt[NCH], cr[NCH];
+    float sh[NCH], sl[NCH];               // extrema of the rest of the window: the old samples behind the write index and every other block
+    int cnt[NCH], cr[NCH];                // packed count / sign (see KWalkState.count), the crossing flag of the slot being overwritten
 };
 // phase 1: every load of the update: call it among the caller's other loads.  (On the call that enters a new block -- every 16th --
 // it also reads the block's 16 old samples and the 2 x 16 summaries and STORES the suffix extrema: a rare, slower path.)
@@ -152,28 +154,20 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
     const int samples = min(calls + 1, W);              // :89-90
     const int bidx = idx / QG_WALK_BLOCK, j0 = idx - bidx * QG_WALK_BLOCK, base = bidx * QG_WALK_BLOCK;
     const int nblocks = (W + QG_WALK_BLOCK - 1) / QG_WALK_BLOCK;
-    const int jn = min(j0 + 1, QG_WALK_BLOCK - 1);      // suffix slot behind the write index (clamped: slot 16 does not exist)
-    const bool has_old = j0 + 1 < QG_WALK_BLOCK;
+    const int pidx = idx > 0 ? idx - 1 : W - 1;         // the previous sample's slot (written by the previous call)
     const int t0 = t[0];                                // t[c] = t0 + c
-    walk_ldv<NCH>(S.prev + t0, in.prev);
-    walk_ldv<NCH>(S.sign + t0, in.psign);
+    walk_ldv<NCH>(S.sig + (size_t)pidx * stride + t0, in.prev);
     walk_ldv<NCH>(S.count + t0, in.cnt);
     walk_ldv<NCH>(S.f_est + t0, in.fe);
     walk_ldv<NCH>(S.a_est + t0, in.ae);
-    walk_ldv<NCH>(S.omax + t0, in.om);
-    walk_ldv<NCH>(S.omin + t0, in.on);
     walk_ldv<NCH>(S.bmax + (size_t)bidx * stride + t0, in.bm);
     walk_ldv<NCH>(S.bmin + (size_t)bidx * stride + t0, in.bn);
-    walk_ldv<NCH>(S.smax + (size_t)jn * stride + t0, in.sh);
-    walk_ldv<NCH>(S.smin + (size_t)jn * stride + t0, in.sl);
+    walk_ldv<NCH>(S.smax + (size_t)(j0 + 1) * stride + t0, in.sh);       // slot j0 + 1 <= 16: what stands behind the sample this call writes
+    walk_ldv<NCH>(S.smin + (size_t)(j0 + 1) * stride + t0, in.sl);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        in.cr[c] = (int)S.cross[(size_t)idx * stride + t0 + c];     // the slot holds 0 until the buffer wraps
-        in.sh[c] = has_old ? in.sh[c] : QG_WALK_EMPTY_MAX;
-        in.sl[c] = has_old ? in.sl[c] : QG_WALK_EMPTY_MIN;
-    }
+    for (int c = 0; c < NCH; ++c) in.cr[c] = (int)S.cross[(size_t)idx * stride + t0 + c];     // the slot holds 0 until the buffer wraps
     if (calls > 0 && j0 == 0) {                         // the write index enters block bidx
-        // (a) the cache of the other blocks is rebuilt from the summaries
+        // (a) the extrema of the other blocks, from the summaries
         float hi[NCH][QG_WALK_MAXBLOCKS], lo[NCH][QG_WALK_MAXBLOCKS];
 #pragma unroll
         for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // every summary slot exists (at least 16 blocks are allocated whatever the window): plain loads ...
@@ -185,16 +179,16 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
         }
         // windows of more than 256 samples (frame_skip 1 - 3 at the reference's 2 ms timestep: 1000 / 500 / 334): the summaries
         // past the sixteenth in a rolled loop -- a chain of loads, but only on every sixteenth call and only for such windows
-        float xm[NCH], xn[NCH];
+        float om[NCH], on[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) { xm[c] = QG_WALK_EMPTY_MAX; xn[c] = QG_WALK_EMPTY_MIN; }
+        for (int c = 0; c < NCH; ++c) { om[c] = QG_WALK_EMPTY_MAX; on[c] = QG_WALK_EMPTY_MIN; }
         for (int b = QG_WALK_MAXBLOCKS; b < nblocks; ++b) {
             float h[NCH], l[NCH];
             walk_ldv<NCH>(S.bmax + (size_t)b * stride + t0, h);
             walk_ldv<NCH>(S.bmin + (size_t)b * stride + t0, l);
             const bool use = b != bidx && b * QG_WALK_BLOCK < samples;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { xm[c] = fmaxf(xm[c], use ? h[c] : QG_WALK_EMPTY_MAX); xn[c] = fminf(xn[c], use ? l[c] : QG_WALK_EMPTY_MIN); }
+            for (int c = 0; c < NCH; ++c) { om[c] = fmaxf(om[c], use ? h[c] : QG_WALK_EMPTY_MAX); on[c] = fminf(on[c], use ? l[c] : QG_WALK_EMPTY_MIN); }
         }
         // (b) the block's old samples: the ring is allocated in whole blocks, so the 16 loads are unconditional
         float old[NCH][QG_WALK_BLOCK];
@@ -206,22 +200,25 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
             for (int c = 0; c < NCH; ++c) old[c][j] = o[c];
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) { in.om[c] = xm[c]; in.on[c] = xn[c]; }
-#pragma unroll
         for (int b = 0; b < QG_WALK_MAXBLOCKS; ++b) {   // ... then selects
             const bool use = b < nblocks && b != bidx && b * QG_WALK_BLOCK < samples;      // blocks that hold at least one filled slot
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                in.om[c] = fmaxf(in.om[c], use ? hi[c][b] : QG_WALK_EMPTY_MAX);
-                in.on[c] = fminf(in.on[c], use ? lo[c][b] : QG_WALK_EMPTY_MIN);
+                om[c] = fmaxf(om[c], use ? hi[c][b] : QG_WALK_EMPTY_MAX);
+                on[c] = fminf(on[c], use ? lo[c][b] : QG_WALK_EMPTY_MIN);
             }
         }
-        // suffix extrema of the old samples, filled slots only (slot < samples: none before the buffer has wrapped, and the last
-        // block of a window that is not a multiple of 16 ends early); slot j is stored for the call that writes sample j - 1
+        // the other blocks alone (slot 16), then joined by the suffixes of the old samples, filled slots only (slot < samples: none
+        // before the buffer has wrapped, and the last block of a window that is not a multiple of 16 ends early); slot j is stored
+        // for the call that writes sample j - 1
         {
             float sh[NCH], sl[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { sh[c] = QG_WALK_EMPTY_MAX; sl[c] = QG_WALK_EMPTY_MIN; }
+            for (int c = 0; c < NCH; ++c) { sh[c] = om[c]; sl[c] = on[c]; }
+            if (live) {
+                walk_stv<NCH>(S.smax + (size_t)QG_WALK_BLOCK * stride + t0, sh);
+                walk_stv<NCH>(S.smin + (size_t)QG_WALK_BLOCK * stride + t0, sl);
+            }
 #pragma unroll
             for (int j = QG_WALK_BLOCK - 1; j >= 1; --j) {
                 const bool valid = base + j < samples;
@@ -255,14 +252,12 @@ __device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, co
         for (int c = 0; c < NCH; ++c) { f_new[c] = in.fe[c]; a_new[c] = in.ae[c]; }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            S.prev[t[c]] = x[c];
             S.sig[(size_t)idx * stride + t[c]] = x[c];
+            S.count[t[c]] = 1;                          // no sign change yet, derivative sign 0
             S.bmax[t[c]] = x[c];                        // block 0 holds exactly this sample
             S.bmin[t[c]] = x[c];
-            S.omax[t[c]] = QG_WALK_EMPTY_MAX;
-            S.omin[t[c]] = QG_WALK_EMPTY_MIN;
 #pragma unroll
-            for (int j = 1; j < QG_WALK_BLOCK; ++j) {   // nothing stands behind the write index of block 0 yet
+            for (int j = 1; j <= QG_WALK_BLOCK; ++j) {  // nothing stands behind the write index of block 0 yet, and there is no other block
                 S.smax[(size_t)j * stride + t[c]] = QG_WALK_EMPTY_MAX;
                 S.smin[(size_t)j * stride + t[c]] = QG_WALK_EMPTY_MIN;
             }
@@ -274,35 +269,33 @@ __device__ __forceinline__ void walk_estimator_finish_n(const KWalkParams &P, co
     const bool enter = j0 == 0;
     const float rdur = walk_rcp((float)samples * P.dt); // :109
     const int t0 = t[0];                                // t[c] = t0 + c
-    float mxs[NCH], mns[NCH], curs[NCH], xs[NCH];
+    float mxs[NCH], mns[NCH], xs[NCH];
     int counts[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
+        const float psign = (float)((in.cnt[c] & 3) - 1);                       // the previous derivative sign, packed with the count
         float d = x[c] - in.prev[c];
         float cur = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
         const bool have_sign = calls >= 2;              // a previous derivative sign exists (:78-86)
-        cur = (have_sign && cur == 0.f) ? in.psign[c] : cur;
-        const int crossing = (have_sign && cur != in.psign[c]) ? 1 : 0;
-        const int count = in.cnt[c] - in.cr[c] + crossing;                      // :94-96
+        cur = (have_sign && cur == 0.f) ? psign : cur;
+        const int crossing = (have_sign && cur != psign) ? 1 : 0;
+        const int count = (in.cnt[c] >> 2) - in.cr[c] + crossing;               // :94-96
         const float f_cur = (0.5f * (float)count) * rdur;                       // :113-114
         // the samples written into this block so far, the new one included ...
         const float mx = enter ? x[c] : fmaxf(in.bm[c], x[c]);
         const float mn = enter ? x[c] : fminf(in.bn[c], x[c]);
-        // ... the old ones still standing behind it, and every other block
-        const float amp = fmaxf(fmaxf(mx, in.sh[c]), in.om[c]) - fminf(fminf(mn, in.sl[c]), in.on[c]);   // :121-126
+        // ... and the rest of the window: the old samples still standing behind it and every other block
+        const float amp = fmaxf(mx, in.sh[c]) - fminf(mn, in.sl[c]);           // :121-126
         f_new[c] = P.ema_alpha * in.fe[c] + (1.f - P.ema_alpha) * f_cur;        // :117
         a_new[c] = P.ema_alpha * in.ae[c] + (1.f - P.ema_alpha) * amp;          // :129
         S.cross[(size_t)idx * stride + t0 + c] = (uint8_t)crossing;
-        counts[c] = count; mxs[c] = mx; mns[c] = mn; curs[c] = cur; xs[c] = x[c];
+        counts[c] = 4 * count + ((int)cur + 1); mxs[c] = mx; mns[c] = mn; xs[c] = x[c];
     }
     walk_stv<NCH>(S.count + t0, counts);
-    walk_stv<NCH>(S.sig + (size_t)idx * stride + t0, xs);                       // :99
-    walk_stv<NCH>(S.prev + t0, xs);                                             // :105-106
-    walk_stv<NCH>(S.sign + t0, curs);
+    walk_stv<NCH>(S.sig + (size_t)idx * stride + t0, xs);                       // :99 (and the next call's previous sample, :105-106)
     walk_stv<NCH>(S.f_est + t0, f_new);
     walk_stv<NCH>(S.bmax + (size_t)bidx * stride + t0, mxs);                    // the block's summary once the write index has moved on
     walk_stv<NCH>(S.bmin + (size_t)bidx * stride + t0, mns);
-    if (enter) { walk_stv<NCH>(S.omax + t0, in.om); walk_stv<NCH>(S.omin + t0, in.on); }
     walk_stv<NCH>(S.a_est + t0, a_new);
 }
 
