@@ -241,34 +241,42 @@ __device__ __forceinline__ void po_emit_rows(const KPoParams &P, const KPoState 
     }
 }
 
+// 8- and 16-byte accesses of the copy: vector types (a struct cannot be assigned across address spaces), declared with the alignment
+// the data really has -- rows are 8-byte aligned within their buffers, the caller's `out` is only promised to be 4-byte aligned
+typedef float PoF2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float PoF4 __attribute__((ext_vector_type(4), aligned(4)));
 // ---- the fused form (qg_step_kernel_link<WALK, PO>): the same output in two parts -------------------------------------------------
 // Part 1, in the step kernel's PROLOGUE: the W - 1 frames the new stack keeps are known before the physics runs, so they are copied
 // ring -> out there, their loads in flight together with the state loads (a wave that is alone on its SIMD would otherwise sit
-// through their latency in the epilogue, behind the stores of the step).  `slot` = ring slot the NEW frame will take.  One trip of 16 loads + 16 stores per lane covers obs_window <= 10.
+// through their latency in the epilogue, behind the stores of the step).  `slot` = ring slot the NEW frame will take.  With the ring
+// kept twice (KPoState.stack) the new row is ONE contiguous run of it, from the oldest frame that stays: the env's 16 lanes copy it in
+// 16-byte groups, group g to lane g mod 16 -- five loads and five stores per lane at window 10 (round 2: sixteen 4-byte ones each,
+// with a wrap test per element).  The row is copied WHOLE: its last 26 values receive the frame that is about to be dropped and are
+// overwritten by the new frame in the epilogue (po_emit_new: same wave, program order).
 __device__ __forceinline__ void po_copy_history(const KPoParams &P, const KPoState &S, size_t row, int slot, int l16,
                                                 float *__restrict__ out, bool live = true) {
-    // the new row is the ring rotated: out[r] = ring[(r + 26 * (slot + 1)) mod (26 W)] for r < 26 (W - 1).  Lanes past the end
-    // repeat element 26 (W - 1) - 1 (same value to the same address: harmless), so that no load is predicated; the lanes of a
-    // wave's tail (no env of their own, `live` false) shadow the last env's loads and store nothing -- a whole env is live or not,
-    // so the predicate costs no divergence inside an env, and nothing then orders a shadow copy against the epilogue of the wave
-    // that owns the env.
-    const int W = P.window, width = W * QG_PO_FRAME, hist = width - QG_PO_FRAME;
-    const int off = (slot + 1 >= W ? 0 : slot + 1) * QG_PO_FRAME;
-    const float *__restrict__ st = S.stack + 2 * row;                      // rows of the ring are two windows long
-    float *__restrict__ o = out + row;
-    for (int r0 = l16; r0 < hist; r0 += 256) {
-        float v[16];
-        int rr[16];
+    // Lanes past the end repeat the row's last group (same value to the same address: harmless), so that no load is predicated; the
+    // lanes of a wave's tail (no env of their own, `live` false) shadow the last env's loads and store nothing -- a whole env is live
+    // or not, so the predicate costs no divergence inside an env, and nothing then orders a shadow copy against the epilogue of the
+    // wave that owns the env.
+    const int W = P.window, wbytes = W * QG_PO_FRAME * 4;
+    const int first = slot + 1 >= W ? 0 : slot + 1;                        // the oldest frame that stays
+    const char *src = reinterpret_cast<const char *>(S.stack + 2 * row) + first * (QG_PO_FRAME * 4);
+    char *dst = reinterpret_cast<char *>(out + row);
+    const int groups = wbytes >> 4;
+    for (int g0 = l16; g0 < groups; g0 += 64) {
+        PoF4 v[4];
+        int gg[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            rr[u] = min(r0 + 16 * u, hist - 1);
-            int src = rr[u] + off;
-            if (src >= width) src -= width;
-            v[u] = st[src];
+        for (int u = 0; u < 4; ++u) {
+            gg[u] = min(g0 + 16 * u, groups - 1);
+            v[u] = *reinterpret_cast<const PoF4 *>(src + 16 * gg[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) if (live) o[rr[u]] = v[u];
+        for (int u = 0; u < 4; ++u) if (live) *reinterpret_cast<PoF4 *>(dst + 16 * gg[u]) = v[u];
     }
+    if ((wbytes & 8) && l16 == 15 && live)                                  // odd windows: the row's last 8 bytes
+        *reinterpret_cast<PoF2 *>(dst + wbytes - 8) = *reinterpret_cast<const PoF2 *>(src + wbytes - 8);
 }
 // Phase 1 of the fused form: the 16 lanes of the env run it together.  The filter update is redundant in all of them (no lane has
 // anything else to do); the four inverse trigonometric evaluations of the frame -- roll, yaw, the heading angle of the command
@@ -379,10 +387,6 @@ __device__ __forceinline__ void po_emit_new(const KPoParams &P, const KPoState &
 // WHOLE: its last 26 values receive the frame that is about to be dropped and are overwritten by the new frame in the epilogue (same
 // wave, program order).  What does not fit into frame_skip x K groups per lane is copied after the loop; the one group (and, for
 // odd windows, the 8-byte half) that only some of the env's lanes have travels with the first substep's batch.
-// 8- and 16-byte accesses of the copy: vector types (a struct cannot be assigned across address spaces), declared with the alignment
-// the data really has -- rows are 8-byte aligned within their buffers, the caller's `out` is only promised to be 4-byte aligned
-typedef float PoF2 __attribute__((ext_vector_type(2), aligned(4)));
-typedef float PoF4 __attribute__((ext_vector_type(4), aligned(4)));
 // a pointer every lane of the wave agrees on, into scalar registers -- and typed as GLOBAL memory: after the round trip through
 // integers the compiler no longer knows the address space and would fall back to flat_load / flat_store with 64-bit vector addresses;
 // with it, accesses take the form  global_load v, v_offset32, s[base] offset:imm
