@@ -41,6 +41,39 @@ DEV float env_sum(float x) {
     return x;
 }
 DEV V3 env_sum(V3 a) { return v3(env_sum(a.x), env_sum(a.y), env_sum(a.z)); }
+// Sums of 4 G values over the env's 16 lanes in 2 G + 2 DPP instructions per group of four instead of 16, the butterfly TRANSPOSED
+// through the bank mask of the DPP adds (a bank = 4 consecutive lanes; a masked DPP add writes the enabled banks only and leaves the
+// rest of vdst alone -- the compiler's DPP combiner cannot express that, hence the assembly): of a group (a, b, c, d)
+//   row_half_mirror (banks 0<->1, 2<->3): a's partial sums into banks 0 and 2 of one register, b's into its banks 1 and 3 (c, d alike);
+//   row_ror:8 (banks 0<->2, 1<->3):       banks 0/1 of the result from the (a|b) register, banks 2/3 from the (c|d) register;
+//   the two quad_perm levels on that ONE register.
+// v[4g] returns the group's sums: bank k (lanes 4k .. 4k+3) holds the sum of v[4g + k], the same bits in its four lanes; the consumer
+// fetches them with row_newbcast:4k as the DPP operand of the add that accumulates them (banked_sum<k>).  v[4g + 2] is clobbered.
+// Hazards (a DPP read needs 2 wait states behind a VALU write of the same register; the hazard recogniser does not look into inline
+// assembly): s_nop 1 at both ends, and inside the block the order keeps >= 2 instructions between a write and its DPP read (G >= 3).
+#define QG_T_HM(d, s, bm) "v_add_f32_dpp %[" d "], %[" s "], %[" s "] row_half_mirror row_mask:0xf bank_mask:" bm "\n\t"
+#define QG_T_ROR(d, s, bm) "v_add_f32_dpp %[" d "], %[" s "], %[" s "] row_ror:8 row_mask:0xf bank_mask:" bm "\n\t"
+#define QG_T_QP(d, qp) "v_add_f32_dpp %[" d "], %[" d "], %[" d "] quad_perm:" qp " row_mask:0xf bank_mask:0xf\n\t"
+#define QG_T_L1(g) QG_T_HM("a" g, "a" g, "0x5") QG_T_HM("c" g, "c" g, "0x5") QG_T_HM("a" g, "b" g, "0xa") QG_T_HM("c" g, "d" g, "0xa")
+#define QG_T_L2(g) QG_T_ROR("a" g, "a" g, "0x3") QG_T_ROR("a" g, "c" g, "0xc")
+#define QG_T_Q1(g) QG_T_QP("a" g, "[1,0,3,2]")
+#define QG_T_Q2(g) QG_T_QP("a" g, "[2,3,0,1]")
+#define QG_T_OUT(g, v) [a##g] "+v"(v[4 * g]), [c##g] "+v"(v[4 * g + 2])
+#define QG_T_IN(g, v) [b##g] "v"(v[4 * g + 1]), [d##g] "v"(v[4 * g + 3])
+DEV void env_sum_banked16(float (&v)[16]) {
+    asm("s_nop 1\n\t" QG_T_L1("0") QG_T_L1("1") QG_T_L1("2") QG_T_L1("3") QG_T_L2("0") QG_T_L2("1") QG_T_L2("2") QG_T_L2("3")
+        QG_T_Q1("0") QG_T_Q1("1") QG_T_Q1("2") QG_T_Q1("3") QG_T_Q2("0") QG_T_Q2("1") QG_T_Q2("2") QG_T_Q2("3") "s_nop 1"
+        : QG_T_OUT(0, v), QG_T_OUT(1, v), QG_T_OUT(2, v), QG_T_OUT(3, v)
+        : QG_T_IN(0, v), QG_T_IN(1, v), QG_T_IN(2, v), QG_T_IN(3, v));
+}
+DEV void env_sum_banked12(float (&v)[12]) {
+    asm("s_nop 1\n\t" QG_T_L1("0") QG_T_L1("1") QG_T_L1("2") QG_T_L2("0") QG_T_L2("1") QG_T_L2("2")
+        QG_T_Q1("0") QG_T_Q1("1") QG_T_Q1("2") QG_T_Q2("0") QG_T_Q2("1") QG_T_Q2("2") "s_nop 1"
+        : QG_T_OUT(0, v), QG_T_OUT(1, v), QG_T_OUT(2, v)
+        : QG_T_IN(0, v), QG_T_IN(1, v), QG_T_IN(2, v));
+}
+// the sum a banked group register holds in bank K, for every lane of the env (a row_newbcast DPP operand of the consuming add)
+template <int K> DEV float banked_sum(float r) { return dpp_any<0x150 + 4 * K>(r); }
 // suffix sum over the links of a leg, lanes r = 0,1,2 (lane 3 must hold 0): lane r gets x_r + x_{r+1} + ... + x_2
 DEV float leg_suffix(float x) {
 #pragma clang fp contract(off)
@@ -280,13 +313,21 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         SV p0;
         Sym6 Ic0;
         frame_body(C, bc, h, p0, Ic0);
-        wsumF = env_sum(wsumF);
-        Ic0.AA.xx += env_sum(Cn.AA.xx); Ic0.AA.yy += env_sum(Cn.AA.yy); Ic0.AA.zz += env_sum(Cn.AA.zz);
-        Ic0.AA.xy += env_sum(Cn.AA.xy); Ic0.AA.xz += env_sum(Cn.AA.xz); Ic0.AA.yz += env_sum(Cn.AA.yz);
-        Ic0.AL.r0 = Ic0.AL.r0 + env_sum(Cn.AL.r0); Ic0.AL.r1 = Ic0.AL.r1 + env_sum(Cn.AL.r1); Ic0.AL.r2 = Ic0.AL.r2 + env_sum(Cn.AL.r2);
-        Ic0.LL.xx += env_sum(Cn.LL.xx); Ic0.LL.yy += env_sum(Cn.LL.yy); Ic0.LL.zz += env_sum(Cn.LL.zz);
-        Ic0.LL.xy += env_sum(Cn.LL.xy); Ic0.LL.xz += env_sum(Cn.LL.xz); Ic0.LL.yz += env_sum(Cn.LL.yz);
-        SV b = {env_sum(rhn.a) - p0.a, env_sum(rhn.l) - p0.l};
+        // the 28 sums over the env's lanes (21 of the block, 6 of the right-hand side, the FRAME's contact weight), banked
+        float t16[16] = {Cn.AA.xx, Cn.AA.yy, Cn.AA.zz, Cn.AA.xy, Cn.AA.xz, Cn.AA.yz, Cn.AL.r0.x, Cn.AL.r0.y,
+                         Cn.AL.r0.z, Cn.AL.r1.x, Cn.AL.r1.y, Cn.AL.r1.z, Cn.AL.r2.x, Cn.AL.r2.y, Cn.AL.r2.z, wsumF};
+        float t12[12] = {Cn.LL.xx, Cn.LL.yy, Cn.LL.zz, Cn.LL.xy, Cn.LL.xz, Cn.LL.yz, rhn.a.x, rhn.a.y, rhn.a.z, rhn.l.x, rhn.l.y, rhn.l.z};
+        env_sum_banked16(t16);
+        env_sum_banked12(t12);
+        Ic0.AA.xx += banked_sum<0>(t16[0]); Ic0.AA.yy += banked_sum<1>(t16[0]); Ic0.AA.zz += banked_sum<2>(t16[0]); Ic0.AA.xy += banked_sum<3>(t16[0]);
+        Ic0.AA.xz += banked_sum<0>(t16[4]); Ic0.AA.yz += banked_sum<1>(t16[4]); Ic0.AL.r0.x += banked_sum<2>(t16[4]); Ic0.AL.r0.y += banked_sum<3>(t16[4]);
+        Ic0.AL.r0.z += banked_sum<0>(t16[8]); Ic0.AL.r1.x += banked_sum<1>(t16[8]); Ic0.AL.r1.y += banked_sum<2>(t16[8]); Ic0.AL.r1.z += banked_sum<3>(t16[8]);
+        Ic0.AL.r2.x += banked_sum<0>(t16[12]); Ic0.AL.r2.y += banked_sum<1>(t16[12]); Ic0.AL.r2.z += banked_sum<2>(t16[12]);
+        wsumF = banked_sum<3>(t16[12]);
+        Ic0.LL.xx += banked_sum<0>(t12[0]); Ic0.LL.yy += banked_sum<1>(t12[0]); Ic0.LL.zz += banked_sum<2>(t12[0]); Ic0.LL.xy += banked_sum<3>(t12[0]);
+        Ic0.LL.xz += banked_sum<0>(t12[4]); Ic0.LL.yz += banked_sum<1>(t12[4]);
+        SV b = {v3(banked_sum<2>(t12[4]) - p0.a.x, banked_sum<3>(t12[4]) - p0.a.y, banked_sum<0>(t12[8]) - p0.a.z),
+                v3(banked_sum<1>(t12[8]) - p0.l.x, banked_sum<2>(t12[8]) - p0.l.y, banked_sum<3>(t12[8]) - p0.l.z)};
         if (__any(wsumF > 0.f)) {         // wave-uniform skip, as in the one-leg-per-lane kernel
             sF = env_sum(sF);
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
@@ -366,7 +407,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
 
     // per-lane constants of link r: selected among the three links' LITERALS (two v_cndmask each, ~90 instructions once per launch)
-    // rather than loaded from a table -- a load round trip behind the state loads cost ~1 us of a 16 us launch.  The spare lane
+    // rather than loaded from a table -- a load round trip behind the state loads cost ~1 us of a 16 us launch in round 1; round 3
+    // tried again with ten wide loads of the model constant issued AHEAD of the state loads: 78 instructions fewer, 0.07 us slower
+    // (11.89 against 11.82 us per step, same box).  The spare lane
     // carries no mass and no inertia; its contact is switched off in the substep.
     LinkRegs K;
     {
@@ -377,7 +420,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         // picked with multiply-adds on 0 / 1 lane masks (exact: x * 1 + 0): three instructions per value with the literals folded into
         // v_mul / v_fmamk, against mov + cndmask + mov + cndmask (a VOP3 select takes no literal)
         const float s0 = rk == 0 ? 1.f : 0.f, s1 = rk == 1 ? 1.f : 0.f, s2 = rk == 2 ? 1.f : 0.f;
-#define QG_SEL(field) (BAKED ? fmaf(s2, L2.field, fmaf(s1, L1.field, s0 * L0.field)) : Lown.field)
+        // a value the three links share (the compiled-in robot's servo and hinge parameters) stays a literal: no register, and the
+        // substep's products of such values fold at compile time (the comparison is on constants of QG_BAKED_MODEL)
+#define QG_SEL(field) (BAKED ? ((L0.field == L1.field && L1.field == L2.field) ? L0.field \
+                                                                               : fmaf(s2, L2.field, fmaf(s1, L1.field, s0 * L0.field))) \
+                             : Lown.field)
         K.mass = ml * QG_SEL(mass);
 #pragma unroll
         for (int i = 0; i < 3; ++i) K.ipos[i] = QG_SEL(ipos[i]);
