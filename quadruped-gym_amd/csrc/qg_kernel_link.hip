@@ -513,10 +513,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             WK.S.eff_actions[(size_t)env * 12 + jch] = a_eff;   // the action actually applied (the PO pack reads it)
         }
     }
+    PoHistRegs phist = {};
     if constexpr (PO) {
         int slot = pin.head + 1;
         if (slot >= PK.P.window) slot = 0;
-        if (PK.P.window > 1) po_copy_history(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live);
+        if (PK.P.window > 1) po_copy_history_load(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live, phist);
     }
 
     float *srow = tile + el * 35;
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         }
         wave_sync();                                         // the four envs of a wave are its own in every phase
         QG_MARK(7);                                  // frame built
+        if (PK.P.window > 1) po_copy_history_store(PK.P, (size_t)env * (PK.P.window * QG_PO_FRAME), lane & 15, PK.out, live, phist);
         po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
     }
     QG_MARK(8);

@@ -251,32 +251,51 @@ typedef float PoF4 __attribute__((ext_vector_type(4), aligned(4)));
 // through their latency in the epilogue, behind the stores of the step).  `slot` = ring slot the NEW frame will take.  With the ring
 // kept twice (KPoState.stack) the new row is ONE contiguous run of it, from the oldest frame that stays: the env's 16 lanes copy it in
 // 16-byte groups, group g to lane g mod 16 -- five loads and five stores per lane at window 10 (round 2: sixteen 4-byte ones each,
-// with a wrap test per element).  The row is copied WHOLE: its last 26 values receive the frame that is about to be dropped and are
+// with a wrap test per element; the 65th group of window 10 cost a second, one-lane pass until the batch became five).  The row is copied WHOLE: its last 26 values receive the frame that is about to be dropped and are
 // overwritten by the new frame in the epilogue (po_emit_new: same wave, program order).
-__device__ __forceinline__ void po_copy_history(const KPoParams &P, const KPoState &S, size_t row, int slot, int l16,
-                                                float *__restrict__ out, bool live = true) {
+// The first 80 groups (five per lane: a whole row up to window 12) are LOADED in the prologue and STORED after the substep loop
+// (po_copy_history_store), so that the copy's memory round trip runs under the physics instead of in front of it; longer rows copy
+// the rest on the spot.
+#define QG_PO_HIST_K 5
+struct PoHistRegs { PoF4 v[QG_PO_HIST_K]; };
+__device__ __forceinline__ const char *po_hist_src(const KPoParams &P, const KPoState &S, size_t row, int slot) {
+    const int first = slot + 1 >= P.window ? 0 : slot + 1;               // the oldest frame that stays
+    return reinterpret_cast<const char *>(S.stack + 2 * row) + first * (QG_PO_FRAME * 4);
+}
+__device__ __forceinline__ void po_copy_history_load(const KPoParams &P, const KPoState &S, size_t row, int slot, int l16,
+                                                     float *__restrict__ out, bool live, PoHistRegs &H) {
     // Lanes past the end repeat the row's last group (same value to the same address: harmless), so that no load is predicated; the
     // lanes of a wave's tail (no env of their own, `live` false) shadow the last env's loads and store nothing -- a whole env is live
     // or not, so the predicate costs no divergence inside an env, and nothing then orders a shadow copy against the epilogue of the
     // wave that owns the env.
-    const int W = P.window, wbytes = W * QG_PO_FRAME * 4;
-    const int first = slot + 1 >= W ? 0 : slot + 1;                        // the oldest frame that stays
-    const char *src = reinterpret_cast<const char *>(S.stack + 2 * row) + first * (QG_PO_FRAME * 4);
+    const int wbytes = P.window * QG_PO_FRAME * 4;
+    const char *src = po_hist_src(P, S, row, slot);
     char *dst = reinterpret_cast<char *>(out + row);
     const int groups = wbytes >> 4;
-    for (int g0 = l16; g0 < groups; g0 += 64) {
-        PoF4 v[4];
-        int gg[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < QG_PO_HIST_K; ++u) H.v[u] = *reinterpret_cast<const PoF4 *>(src + 16 * min(l16 + 16 * u, groups - 1));
+    for (int g0 = l16 + 16 * QG_PO_HIST_K; g0 < groups; g0 += 16 * QG_PO_HIST_K) {      // windows past 12: the rest, now
+        PoF4 v[QG_PO_HIST_K];
+        int gg[QG_PO_HIST_K];
+#pragma unroll
+        for (int u = 0; u < QG_PO_HIST_K; ++u) {
             gg[u] = min(g0 + 16 * u, groups - 1);
             v[u] = *reinterpret_cast<const PoF4 *>(src + 16 * gg[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (live) *reinterpret_cast<PoF4 *>(dst + 16 * gg[u]) = v[u];
+        for (int u = 0; u < QG_PO_HIST_K; ++u) if (live) *reinterpret_cast<PoF4 *>(dst + 16 * gg[u]) = v[u];
     }
     if ((wbytes & 8) && l16 == 15 && live)                                  // odd windows: the row's last 8 bytes
         *reinterpret_cast<PoF2 *>(dst + wbytes - 8) = *reinterpret_cast<const PoF2 *>(src + wbytes - 8);
+}
+// after the substep loop and BEFORE po_emit_new (same wave, program order: the new frame then lands on the row's tail, and an env
+// that finished overwrites the whole row)
+__device__ __forceinline__ void po_copy_history_store(const KPoParams &P, size_t row, int l16, float *__restrict__ out, bool live,
+                                                      const PoHistRegs &H) {
+    char *dst = reinterpret_cast<char *>(out + row);
+    const int groups = (P.window * QG_PO_FRAME * 4) >> 4;
+#pragma unroll
+    for (int u = 0; u < QG_PO_HIST_K; ++u) if (live) *reinterpret_cast<PoF4 *>(dst + 16 * min(l16 + 16 * u, groups - 1)) = H.v[u];
 }
 // Phase 1 of the fused form: the 16 lanes of the env run it together.  The filter update is redundant in all of them (no lane has
 // anything else to do); the four inverse trigonometric evaluations of the frame -- roll, yaw, the heading angle of the command
