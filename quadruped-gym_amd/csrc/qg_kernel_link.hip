@@ -591,10 +591,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         if (row == 35) {
             for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
         } else {
-            for (int e = lane; e < total; e += QGK_WAVE) {
-                int er = e / row, ec = e - er * row;
-                dst[e] = tile[er * 35 + ec];
-            }
+            // a row of the tile per pass (row < 64 lanes; the rows of a wave's envs are consecutive in `dst`): no division by `row`
+            for (int er = 0; er < live_envs; ++er)
+                if (lane < row) dst[er * row + lane] = tile[er * 35 + lane];
         }
     }
     QG_MARK(3);                                      // obs tile written out

@@ -1391,8 +1391,10 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
         if (row == 35) {                       // rows were staged with a stride of 35 floats: the packed full layout is a straight copy
             for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
         } else {
+            // e / row without a division per element: row is 21, 23 or 33 here and e < 2^11, where (e * ceil(2^16 / row)) >> 16 is exact
+            const unsigned magic = row == 33 ? 1986u : row == 21 ? 3121u : row == 23 ? 2850u : (65536u + row - 1) / row;
             for (int e = lane; e < total; e += QGK_WAVE) {
-                int er = e / row, ec = e - er * row;
+                const int er = (int)(((unsigned)e * magic) >> 16), ec = e - er * row;
                 dst[e] = tile[er * 35 + ec];
             }
         }
@@ -1786,8 +1788,10 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
         if (row == 35) {
             for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
         } else {
+            // e / row without a division per element: row is 21, 23 or 33 here and e < 2^11, where (e * ceil(2^16 / row)) >> 16 is exact
+            const unsigned magic = row == 33 ? 1986u : row == 21 ? 3121u : row == 23 ? 2850u : (65536u + row - 1) / row;
             for (int e = lane; e < total; e += QGK_WAVE) {
-                int er = e / row, ec = e - er * row;
+                const int er = (int)(((unsigned)e * magic) >> 16), ec = e - er * row;
                 dst[e] = tile[er * 35 + ec];
             }
         }
