@@ -306,7 +306,12 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
         dim3 lg(lblocks), lb(QGK_WAVE * QGK_LINK_WAVES);
-        if (po && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, true, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+        // helper waves (qg_step_kernel_link<.., HELP>): the compiled-in robot's walking forms; QG_LINK_HELPERS=0 runs the one-role kernels
+        static const int helpers = [] { const char *e = getenv("QG_LINK_HELPERS"); return e ? atoi(e) : 1; }();
+        const dim3 lb2(2 * QGK_WAVE * QGK_LINK_WAVES);
+        if (helpers && po && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, true, true, true>), lg, lb2, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+        else if (helpers && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, false, true, true>), lg, lb2, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+        else if (po && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, true, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, *po);
         else if (po) hipLaunchKernelGGL((qg_step_kernel_link<true, true, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, *po);
         else if (s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, false, true>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         else hipLaunchKernelGGL((qg_step_kernel_link<true, false, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});

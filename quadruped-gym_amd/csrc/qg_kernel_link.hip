@@ -371,18 +371,24 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
 // layout (thread = 16 * local env + l16): the frames the new stack keeps are copied ring -> out in the prologue, the env's lead lane
 // runs the orientation filter on the step's sensors in the epilogue, the 16 lanes of the env write the new frame.  The 33 sensors
 // themselves are not written to memory at all.
-template <bool WALK = false, bool PO = false, bool BAKED = true>
-__global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_link(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
+// HELP (with WALK): four more waves per workgroup, one beside each physics wave on its SIMD, run what the step needs that does not depend
+// on its physics -- the estimator update of the env's twelve channels (and the history copy of the observation pack) -- while the
+// physics wave, which alone uses its SIMD's issue slots every fourth cycle only, goes straight into the substep loop; the estimates
+// come back through LDS behind one workgroup barrier after the loop.  Same lane mapping in both waves (lane r < 3 of leg k = channel
+// 3k + r of env el of wave w).
+template <bool WALK = false, bool PO = false, bool BAKED = true, bool HELP = false>
+__global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void qg_step_kernel_link(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
                                                                                   const typename WalkArgT<WALK>::type WK,
                                                                                   const typename PoArgT<PO>::type PK) {
     static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
+    static_assert(WALK || !HELP, "the helper waves carry the walking task layer's estimator");
     static_assert(QGK_LINK_ENVS * QGK_LINK_WAVES == QG_PO_ENVS && QGK_WAVE * QGK_LINK_WAVES == QG_PO_THREADS, "workgroup layout of qg_po_dev.h");
     __shared__ float tile_all[QGK_LINK_WAVES][QGK_LINK_ENVS * 35];
     __shared__ KModel smodel;
     if constexpr (!BAKED) {                         // any other robot: the model tables staged in LDS, read with per-lane (leg) addresses
         const float *src = reinterpret_cast<const float *>(Mp);
         float *dst = reinterpret_cast<float *>(&smodel);
-        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * QGK_LINK_WAVES) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1)) dst[i] = src[i];
         __syncthreads();
     }
     const KModel &C = BAKED ? QG_BAKED_MODEL : smodel;
@@ -393,7 +399,8 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
                                                T->fall_height, T->w_forward, T->w_ctrl, T->alive_bonus, T->default_ctrl};
     QG_MARK(0);
     const int lane = threadIdx.x & (QGK_WAVE - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = (threadIdx.x >> 6) & (QGK_LINK_WAVES - 1);      // HELP: waves 4 .. 7 shadow waves 0 .. 3
+    const bool helper = HELP && (threadIdx.x >> 6) >= QGK_LINK_WAVES;
     float *tile = tile_all[wave];
     const int r = lane & 3;                         // link of this lane (3: spare)
     const int k = (lane >> 2) & 3;                  // leg
@@ -405,6 +412,36 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     const bool lead_env = (lane & 15) == 0;
     const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
     const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
+
+    __shared__ float s_est[HELP ? QGK_LINK_WAVES : 1][QGK_WAVE][2];      // HELP: (f_est, a_est) of the lane's channel, helper -> physics wave
+    if constexpr (HELP) {
+        if (helper) {
+            const int rk = r < 3 ? r : 2, jch = 3 * k + rk;
+            const int tt[1] = {env * 12 + jch};
+            float wf[1] = {0.f}, wa[1] = {0.f};
+            if (r < 3) {
+                const int calls = WK.S.calls[env];
+                const float xx[1] = {P.st.ctrl[jch * n + env]};       // data.ctrl of the PREVIOUS step (walking_quad.py:136)
+                WalkEstIn<1> west;
+                walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west, live);
+                if (live) walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+            }
+            s_est[wave][lane][0] = wf[0];
+            s_est[wave][lane][1] = wa[0];
+            if constexpr (PO) {
+                const PoEnvIn pin = po_env_load(PK.S, n, env);
+                int slot = pin.head + 1;
+                if (slot >= PK.P.window) slot = 0;
+                if (PK.P.window > 1) {
+                    PoHistRegs h;
+                    po_copy_history_load(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live, h);
+                    po_copy_history_store(PK.P, (size_t)env * (PK.P.window * QG_PO_FRAME), lane & 15, PK.out, live, h);
+                }
+            }
+            __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
+            return;
+        }
+    }
 
     // per-lane constants of link r: selected among the three links' LITERALS (two v_cndmask each, ~90 instructions once per launch)
     // rather than loaded from a table -- a load round trip behind the state loads cost ~1 us of a 16 us launch in round 1; round 3
@@ -474,12 +511,14 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     WalkEstIn<1> west;
     if constexpr (WALK) {
         settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
-        calls = WK.S.calls[env];
+        if constexpr (!HELP) calls = WK.S.calls[env];
         wtg = walk_channel_targets(WK.P, jch);
         if (r < 3) {
-            xx[0] = P.st.ctrl[jch * n + env];         // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
             wprev = WK.S.prev_ctrl[tt[0]];            // previous_ctrl of the control cost (:260-262)
-            walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west, live);
+            if constexpr (!HELP) {
+                xx[0] = P.st.ctrl[jch * n + env];     // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+                walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west, live);
+            }
         }
         if (lead_env) {
             win = walk_env_load(WK.S, n, env);
@@ -509,7 +548,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         asm volatile("" :: "v"(B.pw.x), "v"(B.pw.y), "v"(B.pw.z), "v"(B.qw), "v"(B.qx), "v"(B.qy), "v"(B.qz), "v"(B.vw.x), "v"(B.vw.y), "v"(B.vw.z),
                      "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(J.q), "v"(J.qd), "v"(J.act) : "memory");
         if (wch) {
-            walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+            if constexpr (!HELP) walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
             WK.S.eff_actions[(size_t)env * 12 + jch] = a_eff;   // the action actually applied (the PO pack reads it)
         }
     }
@@ -517,7 +556,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     if constexpr (PO) {
         int slot = pin.head + 1;
         if (slot >= PK.P.window) slot = 0;
-        if (PK.P.window > 1) po_copy_history_load(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live, phist);
+        if (!HELP && PK.P.window > 1) po_copy_history_load(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live, phist);
     }
 
     float *srow = tile + el * 35;
@@ -532,6 +571,13 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
     for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
     int nstep = nstep0 + fs;
     QG_MARK(2);                                      // physics done
+    if constexpr (HELP) {
+        // the helper wave of this SIMD finished long ago (its estimator stores and history copy have landed: the barrier's wait
+        // covers them); from here on this wave may overwrite what the helper read (data.ctrl, the ring, the row's tail)
+        __syncthreads();
+        wf[0] = s_est[wave][lane][0];
+        wa[0] = s_est[wave][lane][1];
+    }
 
     const float ssq = env_sum(r < 3 ? aclip * aclip : 0.f);
     float c_fwd = Tk.w_forward * B.vw.x;
@@ -637,7 +683,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         }
         wave_sync();                                         // the four envs of a wave are its own in every phase
         QG_MARK(7);                                  // frame built
-        if (PK.P.window > 1) po_copy_history_store(PK.P, (size_t)env * (PK.P.window * QG_PO_FRAME), lane & 15, PK.out, live, phist);
+        if (!HELP && PK.P.window > 1) po_copy_history_store(PK.P, (size_t)env * (PK.P.window * QG_PO_FRAME), lane & 15, PK.out, live, phist);
         po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
     }
     QG_MARK(8);
