@@ -414,6 +414,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
 
     __shared__ float s_est[HELP ? QGK_LINK_WAVES : 1][QGK_WAVE][2];      // HELP: (f_est, a_est) of the lane's channel, helper -> physics wave
+    __shared__ float s_new[PO ? QG_PO_ENVS : 1][QG_PO_FRAME];     // PO: the frame of this step
+    __shared__ float s_rst[PO ? QG_PO_ENVS : 1][QG_PO_FRAME];     // PO: the frame reset() would return (only for envs that finished)
+    __shared__ int s_slot[PO ? QG_PO_ENVS : 1], s_fin[PO ? QG_PO_ENVS : 1];
+    __shared__ float s_hand[(HELP && PO) ? QG_PO_ENVS : 1][5];    // HELP + PO: done, data.qpos[3:7] as the step leaves it, physics -> helper
     if constexpr (HELP) {
         if (helper) {
             const int rk = r < 3 ? r : 2, jch = 3 * k + rk;
@@ -429,14 +433,32 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
             s_est[wave][lane][0] = wf[0];
             s_est[wave][lane][1] = wa[0];
             if constexpr (PO) {
-                const PoEnvIn pin = po_env_load(PK.S, n, env);
-                int slot = pin.head + 1;
+                const PoEnvIn pin0 = po_env_load(PK.S, n, env);
+                int slot = pin0.head + 1;
                 if (slot >= PK.P.window) slot = 0;
                 if (PK.P.window > 1) {
                     PoHistRegs h;
                     po_copy_history_load(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, lane & 15, PK.out, live, h);
                     po_copy_history_store(PK.P, (size_t)env * (PK.P.window * QG_PO_FRAME), lane & 15, PK.out, live, h);
                 }
+            }
+            if constexpr (PO) {
+                // ... and the observation pack's new frame: the physics wave hands over `done` and the base orientation behind the
+                // barrier and goes on with the state stores and the reward while this wave runs the orientation filter and writes
+                // the rows (the command is the one loaded at kernel entry: a command re-drawn by the physics wave for an env that
+                // finished does not show in this step's frames, as in the one-role kernel)
+                WalkEnvIn hw = {};
+                if (lead_env) hw = walk_env_load(WK.S, n, env);
+                const float hx = __shfl(hw.hx, lane & ~15), hy = __shfl(hw.hy, lane & ~15);
+                const PoEnvIn pin = po_env_load(PK.S, n, env);
+                __syncthreads();
+                const int le = 4 * wave + el;
+                if (live)
+                    po_frame_env16(PK.P, PK.S, n, env, lane & 15, lead_env, pin, tile + el * 35, s_hand[le][1], s_hand[le][2], s_hand[le][3],
+                                   s_hand[le][4], hw.cvx, hw.cvy, hx, hy, s_hand[le][0] != 0.f, s_new[le], s_rst[le], &s_slot[le], &s_fin[le]);
+                wave_sync();
+                po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
+                return;
             }
             __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
             return;
@@ -571,13 +593,6 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
     int nstep = nstep0 + fs;
     QG_MARK(2);                                      // physics done
-    if constexpr (HELP) {
-        // the helper wave of this SIMD finished long ago (its estimator stores and history copy have landed: the barrier's wait
-        // covers them); from here on this wave may overwrite what the helper read (data.ctrl, the ring, the row's tail)
-        __syncthreads();
-        wf[0] = s_est[wave][lane][0];
-        wa[0] = s_est[wave][lane][1];
-    }
 
     const float ssq = env_sum(r < 3 ? aclip * aclip : 0.f);
     float c_fwd = Tk.w_forward * B.vw.x;
@@ -609,6 +624,22 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         B.vw = v3(0.f, 0.f, 0.f);
         B.wb = v3(0.f, 0.f, 0.f);
         nstep = 0;
+    }
+    if constexpr (HELP) {
+        if constexpr (PO) {
+            const int le = 4 * wave + el;
+            if (wch) s_new[le][11 + jch] = aclip;            // data.ctrl of the frame: the env-clipped action this step applied
+            if (lead_env) {                                  // an aliasing estimate shows data.qpos[3:7] as the step leaves it: B after the auto-reset
+                s_hand[le][0] = done ? 1.f : 0.f;
+                s_hand[le][1] = B.qw; s_hand[le][2] = B.qx; s_hand[le][3] = B.qy; s_hand[le][4] = B.qz;
+            }
+        }
+        // the helper wave of this SIMD finished its first job long ago (its estimator stores and history copy have landed: the barrier's
+        // wait covers them); from here on this wave may overwrite what the helper read at entry (data.ctrl, the task state), and the
+        // helper builds the observation pack's frame from the sensor tile, which nothing changes any more
+        __syncthreads();
+        wf[0] = s_est[wave][lane][0];
+        wa[0] = s_est[wave][lane][1];
     }
     if (lead) {
         P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
@@ -664,10 +695,11 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         P.comps[(size_t)env * 3 + 2] = c_alive;
     }
     QG_MARK(6);
-    if constexpr (PO) {
-        __shared__ float s_new[QG_PO_ENVS][QG_PO_FRAME];     // the frame of this step
-        __shared__ float s_rst[QG_PO_ENVS][QG_PO_FRAME];     // the frame reset() would return (only for envs that finished)
-        __shared__ int s_slot[QG_PO_ENVS], s_fin[QG_PO_ENVS];
+    if constexpr (PO && HELP) {
+        // the frame and the rows are the helper wave's; the new episode's command is drawn here (the helper shows the old one)
+        if (live && lead_env && done && Tk.auto_reset && PK.sample)
+            walk_sample_command(WK.P, WK.S, n, env, P.seed, P.env_index_base, win.episode_key);
+    } else if constexpr (PO) {
         const int le = threadIdx.x >> 4;                     // = 4 * wave + el
         if (wch) s_new[le][11 + jch] = aclip;                // data.ctrl of the frame: the env-clipped action this step applied
         if (live) {
