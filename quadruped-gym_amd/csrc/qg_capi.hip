@@ -253,7 +253,8 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
 static int effective_mapping(const qg_sim *s) {
     if (s->mapping == QG_MAP_LANE || s->mapping == QG_MAP_QUAD) return s->mapping;
     if (s->mapping == QG_MAP_PAIR) return s->baked ? QG_MAP_PAIR : QG_MAP_QUAD;
-    if (s->mapping == QG_MAP_LINK) return s->task.sensor_lag ? QG_MAP_LINK : QG_MAP_QUAD;
+    // (the one-link-per-lane kernel addresses the state with 32-bit byte offsets from scalar bases: 19 n floats must stay below 4 GiB)
+    if (s->mapping == QG_MAP_LINK) return (s->task.sensor_lag && s->n <= (1 << 24)) ? QG_MAP_LINK : QG_MAP_QUAD;
     // up to 4096 envs: 1024 waves of the one-link-per-lane kernel = one per SIMD
     if (s->task.sensor_lag && s->n <= 1024 * QGK_LINK_ENVS) return QG_MAP_LINK;
     if (s->baked && s->n > 1024 * QGK_QUAD_ENVS && (s->n <= 1024 * QGK_PAIR_ENVS || s->n >= 1792 * QGK_PAIR_ENVS)) return QG_MAP_PAIR;

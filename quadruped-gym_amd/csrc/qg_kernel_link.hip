@@ -25,6 +25,14 @@
 #define QGK_LINK_ENVS 4     // envs per wave
 #include "qg_po_dev.h"      // partially observable observation pack: per-env device functions of the fused <WALK, PO> variant
 
+// State accesses of this kernel: a scalar base plus a 32-bit BYTE offset per lane (global_load / store v, voff, s[base]) instead of a
+// 64-bit address computed per access -- two to three instructions fewer in front of every load, i.e. the prologue's loads go out
+// sooner (the launcher keeps this mapping to n <= 2^24 envs: 19 n floats stay below 4 GiB).
+typedef const __attribute__((address_space(1))) char *lk_gcbytes;
+typedef __attribute__((address_space(1))) char *lk_gbytes;
+template <class T> DEV T lk_ld(const T *base, unsigned byte_off) { return *(const __attribute__((address_space(1))) T *)((lk_gcbytes)base + byte_off); }
+template <class T> DEV void lk_st(T *base, unsigned byte_off, T v) { *(__attribute__((address_space(1))) T *)((lk_gbytes)base + byte_off) = v; }
+
 template <int CTRL> DEV float dpp_any(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
 }
@@ -507,15 +515,16 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     }
 
     BaseState B;
-    B.pw = v3(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
-    B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
-    B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
-    B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    const unsigned n4 = 4u * (unsigned)n, e4 = 4u * (unsigned)env;        // byte strides of the [field][n] state arrays
+    B.pw = v3(lk_ld(P.st.qpos, e4), lk_ld(P.st.qpos, n4 + e4), lk_ld(P.st.qpos, 2 * n4 + e4));
+    B.qw = lk_ld(P.st.qpos, 3 * n4 + e4); B.qx = lk_ld(P.st.qpos, 4 * n4 + e4); B.qy = lk_ld(P.st.qpos, 5 * n4 + e4); B.qz = lk_ld(P.st.qpos, 6 * n4 + e4);
+    B.vw = v3(lk_ld(P.st.qvel, e4), lk_ld(P.st.qvel, n4 + e4), lk_ld(P.st.qvel, 2 * n4 + e4));
+    B.wb = v3(lk_ld(P.st.qvel, 3 * n4 + e4), lk_ld(P.st.qvel, 4 * n4 + e4), lk_ld(P.st.qvel, 5 * n4 + e4));
     {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised
         const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
         B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
     }
-    const int nstep0 = P.st.nstep[env];
+    const int nstep0 = lk_ld(P.st.nstep, e4);
     // this lane's hinge (the spare lane shadows hinge 2 of its leg: same loads, nothing of it is ever stored)
     const int rk = r < 3 ? r : 2;
     const int jch = 3 * k + rk;                      // hinge = control channel of this lane
@@ -550,7 +559,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     PoEnvIn pin = {};
     if constexpr (PO) pin = po_env_load(PK.S, n, env);      // every lane of the env: the history copy below needs the ring position
     {
-        float a_in = P.actions[(size_t)env * 12 + jch];
+        float a_in = lk_ld(P.actions, 12u * e4 + 4u * (unsigned)jch);
         if constexpr (WALK) {
             if (settle) a_in = wtg.center;                          // the joint centres while the robot settles
             a_eff = a_in;
@@ -561,9 +570,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         const float chi = BAKED ? sel3(rk, C.link[0].ctrl_hi, C.link[1].ctrl_hi, C.link[2].ctrl_hi) : Lj.ctrl_hi;
         const float ref = BAKED ? sel3(rk, C.link[0].ref, C.link[1].ref, C.link[2].ref) : Lj.ref;
         J.u = fminf(fmaxf(aclip, clo), chi);
-        J.q = P.st.qpos[(7 + jch) * n + env];
-        J.qd = P.st.qvel[(6 + jch) * n + env];
-        J.act = P.st.act[jch * n + env];
+        const unsigned j4 = (unsigned)jch * n4 + e4;                        // hinge jch of this env within a [12][n] block
+        J.q = lk_ld(P.st.qpos, 7 * n4 + j4);
+        J.qd = lk_ld(P.st.qvel, 6 * n4 + j4);
+        J.act = lk_ld(P.st.act, j4);
         sincos_f(J.q - ref, J.sn, J.cs);
     }
     if constexpr (WALK) {
@@ -642,19 +652,20 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         wa[0] = s_est[wave][lane][1];
     }
     if (lead) {
-        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
-        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
-        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
-        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
-        P.st.nstep[env] = nstep;
+        lk_st(P.st.qpos, e4, B.pw.x); lk_st(P.st.qpos, n4 + e4, B.pw.y); lk_st(P.st.qpos, 2 * n4 + e4, B.pw.z);
+        lk_st(P.st.qpos, 3 * n4 + e4, B.qw); lk_st(P.st.qpos, 4 * n4 + e4, B.qx); lk_st(P.st.qpos, 5 * n4 + e4, B.qy); lk_st(P.st.qpos, 6 * n4 + e4, B.qz);
+        lk_st(P.st.qvel, e4, B.vw.x); lk_st(P.st.qvel, n4 + e4, B.vw.y); lk_st(P.st.qvel, 2 * n4 + e4, B.vw.z);
+        lk_st(P.st.qvel, 3 * n4 + e4, B.wb.x); lk_st(P.st.qvel, 4 * n4 + e4, B.wb.y); lk_st(P.st.qvel, 5 * n4 + e4, B.wb.z);
+        lk_st(P.st.nstep, e4, nstep);
         if (rst) P.st.episode[env] += 1;
     }
     if (wch) {                                      // every link lane stores its own hinge
         const float q0 = BAKED ? sel3(rk, C.qpos0[7], C.qpos0[8], C.qpos0[9]) : C.qpos0[7 + jch];
-        P.st.qpos[(7 + jch) * n + env] = rst ? q0 : J.q;
-        P.st.qvel[(6 + jch) * n + env] = rst ? 0.f : J.qd;
-        P.st.act[jch * n + env] = rst ? 0.f : J.act;
-        if (P.track_ctrl) P.st.ctrl[jch * n + env] = rst ? Tk.default_ctrl[jch] : aclip;
+        const unsigned j4 = (unsigned)jch * n4 + e4;
+        lk_st(P.st.qpos, 7 * n4 + j4, rst ? q0 : J.q);
+        lk_st(P.st.qvel, 6 * n4 + j4, rst ? 0.f : J.qd);
+        lk_st(P.st.act, j4, rst ? 0.f : J.act);
+        if (P.track_ctrl) lk_st(P.st.ctrl, j4, rst ? Tk.default_ctrl[jch] : aclip);
     }
     if (lead_env) {
         if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
