@@ -45,6 +45,7 @@ struct qg_sim {
     uint64_t seed;
     uint64_t env_index_base;
     int32_t track_ctrl;
+    int32_t link_helpers;     // walking forms of the one-link-per-lane kernel run with helper waves (QG_LINK_HELPERS at qg_create; default 1)
     int32_t baked;            // 1: the model equals the compiled-in default, the literal-constant kernel variant runs
     int32_t mapping;          // QG_MAP_AUTO / QG_MAP_LANE / QG_MAP_QUAD (request)
     int32_t creating;
@@ -152,6 +153,7 @@ extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *mode
     s->task = *task;
     s->env_index_base = env_index_base;
     s->track_ctrl = 1;
+    { const char *e = getenv("QG_LINK_HELPERS"); s->link_helpers = e ? (atoi(e) != 0) : 1; }
     s->mapping = QG_MAP_AUTO;
     if (const char *e = getenv("QG_PO_UNFUSED")) s->po_unfused = atoi(e) != 0;
     if (const char *e = getenv("QG_QUAD_WPE")) {
@@ -307,8 +309,8 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
         int lblocks = (s->n + per_block - 1) / per_block;
         dim3 lg(lblocks), lb(QGK_WAVE * QGK_LINK_WAVES);
-        // helper waves (qg_step_kernel_link<.., HELP>): the compiled-in robot's walking forms; QG_LINK_HELPERS=0 runs the one-role kernels
-        static const int helpers = [] { const char *e = getenv("QG_LINK_HELPERS"); return e ? atoi(e) : 1; }();
+        // helper waves (qg_step_kernel_link<.., HELP>): the compiled-in robot's walking forms; QG_LINK_HELPERS=0 at qg_create keeps the one-role kernels
+        const int helpers = s->link_helpers;
         const dim3 lb2(2 * QGK_WAVE * QGK_LINK_WAVES);
         if (helpers && po && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, true, true, true>), lg, lb2, 0, stream, s->d_model, s->d_task, P, *walk, *po);
         else if (helpers && s->baked) hipLaunchKernelGGL((qg_step_kernel_link<true, false, true, true>), lg, lb2, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});

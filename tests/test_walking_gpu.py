@@ -448,3 +448,55 @@ def test_task_state_snapshot_restores_bit_identical_rollouts(po, n, mapping):
     with pytest.raises((ValueError, _abi.QuadGymError)):
         other.restore(snap)
     env.close(); twin.close(); other.close()
+
+
+@pytest.mark.parametrize("po,n,steps", [(False, 300, 130), (True, 300, 130), (False, 4096, 40), (True, 4090, 40), (True, 37, 60)])
+def test_helper_waves_equal_the_one_role_kernel(po, n, steps, monkeypatch):
+    """qg_step_kernel_link<WALK, .., HELP>: four helper waves per workgroup run the estimator update (and the observation pack's history
+    copy, frame and rows) beside the physics waves.  The two forms (helpers: the default up to 4096 envs; QG_LINK_HELPERS=0 when the
+    simulator is created: the one-role kernel) are different instantiations of the physics, whose contraction choices differ in an ulp
+    here and there, and this robot's contacts amplify an ulp by 1e4 per env-step -- so the comparison is per STEP from IDENTICAL state:
+    before every step the one-role env is restored from the helper env's snapshot.  What does not pass through the physics must then
+    agree to the BIT: the estimator's estimates (they read data.ctrl), the commands, the dones, every frame of the 260-value stack but
+    the newest and the newest frame's data.ctrl / command columns; what does, within one step's amplified rounding (2e-2 absolute,
+    typically 1e-8; 2 m/s² on the accelerometer, whose reading jumps when a contact switches inside the step).  Auto-resets with re-drawn commands, a ragged last workgroup (4090, 37 envs) and a wrap of the estimator's window included."""
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv, WalkingQuadrupedVecEnv
+    kw = dict(settling_time=0.05, frame_skip=10, max_time=0.6, random_init=True, random_controls=True, device_commands=True, seed=5,
+              reset_options={"min_speed": 0.1, "max_speed": 0.4})
+    make = (lambda: POWalkingQuadrupedVecEnv(n, obs_window=10, **kw)) if po else (lambda: WalkingQuadrupedVecEnv(n, **kw))
+    envs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("QG_LINK_HELPERS", flag)
+        e = make()
+        e.reset()
+        envs.append(e)
+    rng = np.random.default_rng(9)
+    resets = 0
+    worst = 0.0
+    for k in range(steps):                                           # the estimator's window at frame_skip 10 is 100 samples
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        envs[1].restore(envs[0].snapshot())
+        (o0, r0, d0, _), (o1, r1, d1, _) = [e.step(a) for e in envs]
+        assert np.array_equal(d0, d1), k
+        fin = d0.astype(bool)
+        if po:
+            o0f, o1f = o0.reshape(n, 10, 26), o1.reshape(n, 10, 26)
+            live = ~fin                                                                # (a finished env shows its reset stack: computed)
+            assert np.array_equal(o0f[live, :9], o1f[live, :9]), k                    # history: copied, not computed
+            assert np.array_equal(o0f[live, 9, 11:], o1f[live, 9, 11:]), k            # data.ctrl and the command of the newest frame
+        live = ~fin
+        acc = slice(9 * 26 + 3, 9 * 26 + 6) if po else slice(12, 15)                   # the accelerometer: contact switches inside the step
+        dd = np.abs(o0[live] - o1[live])
+        assert float(dd[:, acc].max(initial=0.0)) < 2.0, (k, float(dd[:, acc].max()))
+        dd[:, acc] = 0.0
+        assert float(dd.max(initial=0.0)) < 2e-2, (k, float(dd.max()))
+        assert np.allclose(o0[fin], o1[fin], rtol=0, atol=(2e-6 if po else 0.0)), k     # reset observation (PO: Euler angles of the new heading)
+        assert np.allclose(r0, r1, rtol=0, atol=5e-2, equal_nan=True), k
+        assert np.allclose(envs[0].last_components, envs[1].last_components, rtol=0, atol=5e-2, equal_nan=True), k
+        assert all(np.array_equal(x, y) for x, y in zip(envs[0].commands(), envs[1].commands())), k
+        assert all(np.array_equal(x, y) for x, y in zip(envs[0].estimates(), envs[1].estimates())), k
+        worst = max(worst, float(dd.max(initial=0.0)))
+        resets += int(d0.sum())
+    assert resets > 0
+    for e in envs:
+        e.close()
