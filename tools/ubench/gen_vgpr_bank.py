@@ -33,6 +33,12 @@ PATTERNS = [
     ("pk_fma all pairs in banks (0,1)", "v_pk_fma_f32 v[{d}:{d1}], v[{a}:{a1}], v[{b}:{b1}], v[{c}:{c1}]", [(8 + 4 * (i % 2), 16 + 4 * (i % 2), 24 + 4 * (i % 2)) for i in range(8)]),
     ("pk_fma pairs (0,1)(2,3)(2,3)", "v_pk_fma_f32 v[{d}:{d1}], v[{a}:{a1}], v[{b}:{b1}], v[{c}:{c1}]", [(8 + 4 * (i % 2), 14 + 4 * (i % 2), 26 + 4 * (i % 2)) for i in range(8)]),
     ("pk_mul pairs (0,1)(2,3)", "v_pk_mul_f32 v[{d}:{d1}], v[{a}:{a1}], v[{b}:{b1}]", [(8 + 4 * (i % 2), 14 + 4 * (i % 2), 0) for i in range(8)]),
+    # EXEC masks: does a wave64 instruction with an empty half skip that half's pass through the 32-lane SIMD?
+    ("fmac  EXEC = lanes 0-31", "v_fmac_f32_e32 v{d}, v{a}, v{b}", [(9 + i, 14 + i, 0) for i in range(8)], "0xffffffff"),
+    ("fma   EXEC = lanes 0-31", "v_fma_f32 v{d}, v{a}, v{b}, v{c}", [(8 + i, 13 + i, 18 + i) for i in range(8)], "0xffffffff"),
+    ("add_dpp quad_perm, EXEC = lanes 0-31", "v_add_f32_dpp v{d}, v{a}, v{b} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", [(8 + i, 13 + i, 0) for i in range(8)], "0xffffffff"),
+    ("fmac  EXEC = lanes 0-15", "v_fmac_f32_e32 v{d}, v{a}, v{b}", [(9 + i, 14 + i, 0) for i in range(8)], "0xffff"),
+    ("fmac  EXEC = lanes 0-15 and 32-47", "v_fmac_f32_e32 v{d}, v{a}, v{b}", [(9 + i, 14 + i, 0) for i in range(8)], "0x0000ffff0000ffff"),
     ("pk_mul pairs (0,1)(0,1)", "v_pk_mul_f32 v[{d}:{d1}], v[{a}:{a1}], v[{b}:{b1}]", [(8 + 4 * (i % 2), 16 + 4 * (i % 2), 0) for i in range(8)]),
 ]
 
@@ -47,7 +53,7 @@ KERNEL = r'''__global__ __launch_bounds__(64) void k%(idx)d(float *out, unsigned
     unsigned long long r0 = wall_clock64();
     asm volatile(
 %(init)s
-        "s_mov_b64 s[10:11], 0x5555\n\t"
+%(execset)s        "s_mov_b64 s[10:11], 0x5555\n\t"
         "s_mov_b32 s12, 0x3f7fbe77\n\t"
         "s_movk_i32 s13, %(iters)d\n"
         "1:\n\t"
@@ -57,7 +63,8 @@ KERNEL = r'''__global__ __launch_bounds__(64) void k%(idx)d(float *out, unsigned
         "s_cbranch_scc1 1b\n\t"
         "v_add_f32 v40, v40, v41\n\t"
         "global_store_dword %%0, v40, off\n\t"
-        "s_waitcnt vmcnt(0)"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, -1"
         :: "v"(out + blockIdx.x * 64 + threadIdx.x)
         : %(clob)s, "s10", "s11", "s12", "s13", "scc", "memory");
     if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = wall_clock64() - r0;
@@ -68,7 +75,9 @@ KERNEL = r'''__global__ __launch_bounds__(64) void k%(idx)d(float *out, unsigned
 def main():
     out = [HEAD]
     names = []
-    for idx, (name, tmpl, srcs) in enumerate(PATTERNS):
+    for idx, pat in enumerate(PATTERNS):
+        name, tmpl, srcs = pat[:3]
+        execmask = pat[3] if len(pat) > 3 else None
         init = "\n".join('        "v_mov_b32 v%d, 1.0\\n\\t"' % r for r in range(8, 48))
         body = []
         for rep in range(8):
@@ -78,7 +87,11 @@ def main():
                 d = 40 + (2 * (i % 4) if pk else i)
                 body.append('        "' + tmpl.format(d=d, d1=d + 1, a=a, a1=a + 1, b=b, b1=b + 1, c=c, c1=c + 1) + '\\n\\t"')
         clob = ", ".join('"v%d"' % r for r in range(8, 48))
-        out.append(KERNEL % dict(idx=idx, init=init, body="\n".join(body), clob=clob, iters=4096))
+        execset = ""
+        if execmask:
+            lo, hi = int(execmask, 16) & 0xffffffff, int(execmask, 16) >> 32
+            execset = '        "s_mov_b32 exec_lo, 0x%x\\n\\t"\n        "s_mov_b32 exec_hi, 0x%x\\n\\t"\n' % (lo, hi)
+        out.append(KERNEL % dict(idx=idx, init=init, body="\n".join(body), clob=clob, iters=4096, execset=execset))
         names.append(name)
     out.append("typedef void (*kern_t)(float *, unsigned long long *);\n")
     out.append("static kern_t KS[] = {" + ", ".join("k%d" % i for i in range(len(PATTERNS))) + "};\n")
