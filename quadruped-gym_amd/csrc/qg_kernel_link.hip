@@ -676,12 +676,20 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         const int live_envs = max(0, min(QGK_LINK_ENVS, n - env0));     // a whole wave may lie past the last env
         const int total = live_envs * row;
         float *dst = (P.packed ? P.packed : P.obs) + (size_t)env0 * row;
+        // every LDS read of the copy first, then the stores: in a loop with a run-time bound each pass waited out its own LDS latency
         if (row == 35) {
-            for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+            float v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) v[u] = tile[min(lane + u * QGK_WAVE, QGK_LINK_ENVS * 35 - 1)];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) if (lane + u * QGK_WAVE < total) dst[lane + u * QGK_WAVE] = v[u];
         } else {
             // a row of the tile per pass (row < 64 lanes; the rows of a wave's envs are consecutive in `dst`): no division by `row`
-            for (int er = 0; er < live_envs; ++er)
-                if (lane < row) dst[er * row + lane] = tile[er * 35 + lane];
+            float v[QGK_LINK_ENVS];
+#pragma unroll
+            for (int er = 0; er < QGK_LINK_ENVS; ++er) v[er] = tile[er * 35 + min(lane, 34)];
+#pragma unroll
+            for (int er = 0; er < QGK_LINK_ENVS; ++er) if (er < live_envs && lane < row) dst[er * row + lane] = v[er];
         }
     }
     QG_MARK(3);                                      // obs tile written out
