@@ -339,7 +339,10 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
             if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else if (wpe == 1) {
-            if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+            // at most one physics wave per SIMD: helper waves beside them (QG_LINK_HELPERS, as for the one-link-per-lane kernel)
+            if (s->link_helpers && !s->quad_wpe)
+                hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, false, true>), g4, dim3(QGK_WAVE * 8), 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
+            else if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else {
             hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});

@@ -1164,22 +1164,28 @@ DEV void po_wave_epilogue(const KPoLaunch &PK, const KWalkLaunch &WK, const KSte
 // see qg_step_kernel_pair); the waves of a workgroup do not interact.
 // PO (with WALK; round 3): the partially observable observation pack fused in as in qg_step_kernel_pair<.., PO> (history copy on the
 // substep loop, frame by the env's lead lane, new frames written by the wave); the register-capped development variants (WPE > 2) have none.
-template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1, bool PO = false>
-__global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
+// HELP (with WALK, two-waves-per-SIMD register budget, no observation pack): as in qg_step_kernel_link<.., HELP> -- WAVES more waves
+// per workgroup run the estimator update of their partner wave's channels while that wave goes straight into the substep loop; for
+// grids of at most one physics wave per SIMD (<= 16 384 envs), where the partner's issue slots are otherwise idle.
+template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1, bool PO = false, bool HELP = false>
+__global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
                                                                              const typename WalkArgT<WALK>::type WK,
                                                                              const typename PoArgT<PO>::type PK) {
     static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
     static_assert(!(PO && WPE > 2), "no fused observation pack in the register-capped development variants");
+    static_assert(!HELP || (WALK && !PO && WPE == 2), "helper waves: walking without the observation pack, two waves per SIMD");
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
+    __shared__ float s_est[HELP ? WAVES : 1][QGK_WAVE][6];      // HELP: (f_est, a_est) of the lane's three channels, helper -> physics wave
     const int lane = threadIdx.x & (QGK_WAVE - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = HELP ? ((threadIdx.x >> 6) % WAVES) : (threadIdx.x >> 6);      // HELP: waves WAVES .. 2 WAVES - 1 shadow waves 0 .. WAVES - 1
+    const bool helper = HELP && (int)(threadIdx.x >> 6) >= WAVES;
     float *tile = tile_all[wave];
     QG_MARK(0);
     if constexpr (!BAKED) {
         const float *src = reinterpret_cast<const float *>(Mp);
         float *dst = reinterpret_cast<float *>(&smodel);
-        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * WAVES) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * WAVES * (HELP ? 2 : 1)) dst[i] = src[i];
         __syncthreads();
     }
     const KModel &C = BAKED ? QG_BAKED_MODEL : smodel;
@@ -1193,6 +1199,22 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
     const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
 
+    if constexpr (HELP) {
+        if (helper) {
+            const int ht[3] = {env * 12 + 3 * k + 0, env * 12 + 3 * k + 1, env * 12 + 3 * k + 2};
+            const int hcalls = WK.S.calls[env];
+            float hx[3], hf[3] = {0.f, 0.f, 0.f}, ha[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) hx[i] = P.st.ctrl[(3 * k + i) * n + env];   // data.ctrl of the PREVIOUS step (walking_quad.py:136)
+            WalkEstIn<3> hw;
+            walk_estimator_load_n<3, true>(WK.P, WK.S, n, ht, hcalls, hw, live);     // block entry in rolled groups: no scratch at 256 registers
+            if (live) walk_estimator_finish_n<3>(WK.P, WK.S, n, ht, hx, hcalls, hw, hf, ha);    // math_utils.py:53-131
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { s_est[wave][lane][i] = hf[i]; s_est[wave][lane][3 + i] = ha[i]; }
+            __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
+            return;
+        }
+    }
     BaseState B;
     B.pw = v3(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
@@ -1210,7 +1232,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     WalkEnvIn win = {};
     if constexpr (WALK) {
         settle = nstep0 < WK.P.settle_substeps;                     // data.time < settling_time (walking_quad.py:142-143)
-        calls = WK.S.calls[env];
+        if constexpr (!HELP) calls = WK.S.calls[env];
     }
     // WALK: every load of the task layer goes out here, among the state loads, and every store of its prologue part comes after the
     // last load of the kernel's prologue (a load behind a store would wait for that store: vmcnt counts in order)
@@ -1220,9 +1242,9 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
     WalkChanTargets wtg[3] = {};
     if constexpr (WALK) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) xx[i] = P.st.ctrl[(3 * k + i) * n + env];   // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
+        for (int i = 0; i < 3; ++i) if constexpr (!HELP) xx[i] = P.st.ctrl[(3 * k + i) * n + env];   // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
         walk_ldv<3>(WK.S.prev_ctrl + tt[0], wprev);   // previous_ctrl of the control cost (:260-262)
-        walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
+        if constexpr (!HELP) walk_estimator_load_n<3>(WK.P, WK.S, n, tt, calls, west);
         if constexpr (WPE == 1) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) wtg[i] = walk_channel_targets(WK.P, 3 * k + i);
@@ -1269,7 +1291,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
                      "v"(B.wb.x), "v"(B.wb.y), "v"(B.wb.z), "v"(L.q[0]), "v"(L.q[1]), "v"(L.q[2]), "v"(L.qd[0]), "v"(L.qd[1]), "v"(L.qd[2]),
                      "v"(L.act[0]), "v"(L.act[1]), "v"(L.act[2]), "v"(L.u[0]), "v"(L.u[1]), "v"(L.u[2]) : "memory");
         if (live) {
-            walk_estimator_finish_n<3>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
+            if constexpr (!HELP) walk_estimator_finish_n<3>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
             walk_stv<3>(WK.S.eff_actions + (size_t)env * 12 + 3 * k, a_eff);                        // the action actually applied (the PO pack reads it)
         }
     }
@@ -1411,13 +1433,21 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, WPE) void qg_step_kernel_quad(con
 #pragma unroll                        // instead of carrying 21 values through the substep loop
             for (int i = 0; i < 3; ++i) {
                 const int t = env_e * 12 + 3 * k_e + i;
-                wprev[i] = WK.S.prev_ctrl[t]; wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t];
+                wprev[i] = WK.S.prev_ctrl[t];
+                if constexpr (!HELP) { wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t]; }
                 wtg[i] = walk_channel_targets(WK.P, 3 * k_e + i);
             }
             if (lead) {
                 win = walk_env_load(WK.S, n, env_e);
                 win.episode_key = P.st.episode[env_e];
             }
+        }
+        if constexpr (HELP) {
+            // the helper wave of this SIMD finished long ago (its estimator stores have landed: the barrier's wait covers them); from
+            // here on this wave may overwrite what the helper read at entry (data.ctrl)
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { wf[i] = s_est[wave][lane][i]; wa[i] = s_est[wave][lane][3 + i]; }
         }
         if (live) {
 #pragma unroll

@@ -145,7 +145,10 @@ template <int NCH> struct WalkEstIn {
 };
 // phase 1: every load of the update: call it among the caller's other loads.  (On the call that enters a new block -- every 16th --
 // it also reads the block's 16 old samples and the 2 x 16 summaries and STORES the suffix extrema: a rare, slower path.)
-template <int NCH>
+// LOWP: the block-entry path in rolled groups of four loads, reduced as they arrive (max / min: the same bits in any order), for a caller
+// that must fit in 256 registers with nothing to park -- the helper waves of qg_step_kernel_quad<.., HELP>; the unrolled form keeps
+// 2 x 16 summaries and 16 old samples per channel in flight.
+template <int NCH, bool LOWP = false>
 __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, const KWalkState &S, int n, const int (&t)[NCH], int calls, WalkEstIn<NCH> &in,
                                                       bool live = true /* false: a tail lane shadowing the last env -- loads only, no stores */) {
     const int W = P.window;
@@ -166,6 +169,62 @@ __device__ __forceinline__ void walk_estimator_load_n(const KWalkParams &P, cons
     walk_ldv<NCH>(S.smin + (size_t)(j0 + 1) * stride + t0, in.sl);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) in.cr[c] = (int)S.cross[(size_t)idx * stride + t0 + c];     // the slot holds 0 until the buffer wraps
+    if constexpr (LOWP) {
+        if (calls > 0 && j0 == 0) {                     // the write index enters block bidx
+            float sh[NCH], sl[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { sh[c] = QG_WALK_EMPTY_MAX; sl[c] = QG_WALK_EMPTY_MIN; }
+            const int nb = max(nblocks, QG_WALK_MAXBLOCKS);             // summary slots that exist
+#pragma unroll 1
+            for (int b0 = 0; b0 < nb; b0 += 4) {                        // (a) the extrema of the other blocks
+                float h[4][NCH], l[4][NCH];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = min(b0 + u, nb - 1);
+                    walk_ldv<NCH>(S.bmax + (size_t)b * stride + t0, h[u]);
+                    walk_ldv<NCH>(S.bmin + (size_t)b * stride + t0, l[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int b = b0 + u;
+                    const bool use = b < nblocks && b != bidx && b * QG_WALK_BLOCK < samples;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) { sh[c] = fmaxf(sh[c], use ? h[u][c] : QG_WALK_EMPTY_MAX); sl[c] = fminf(sl[c], use ? l[u][c] : QG_WALK_EMPTY_MIN); }
+                }
+                asm volatile("" ::: "memory");                          // the next group's loads stay behind this group's reduction
+            }
+            if (live) {
+                walk_stv<NCH>(S.smax + (size_t)QG_WALK_BLOCK * stride + t0, sh);
+                walk_stv<NCH>(S.smin + (size_t)QG_WALK_BLOCK * stride + t0, sl);
+            }
+#pragma unroll 1
+            for (int j0g = QG_WALK_BLOCK - 4; j0g >= 0; j0g -= 4) {     // (b) joined by the suffixes of the block's old samples, from the top
+                float o[4][NCH];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) walk_ldv<NCH>(S.sig + (size_t)(base + j0g + u) * stride + t0, o[u]);
+#pragma unroll
+                for (int u = 3; u >= 0; --u) {
+                    const int j = j0g + u;
+                    if (j >= 1) {
+                        const bool valid = base + j < samples;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            sh[c] = fmaxf(sh[c], valid ? o[u][c] : QG_WALK_EMPTY_MAX);
+                            sl[c] = fminf(sl[c], valid ? o[u][c] : QG_WALK_EMPTY_MIN);
+                        }
+                        if (live) {
+                            walk_stv<NCH>(S.smax + (size_t)j * stride + t0, sh);
+                            walk_stv<NCH>(S.smin + (size_t)j * stride + t0, sl);
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { in.sh[c] = sh[c]; in.sl[c] = sl[c]; }     // j = 1: what stands behind the sample this call writes
+        }
+        return;
+    }
     if (calls > 0 && j0 == 0) {                         // the write index enters block bidx
         // (a) the extrema of the other blocks, from the summaries
         float hi[NCH][QG_WALK_MAXBLOCKS], lo[NCH][QG_WALK_MAXBLOCKS];

@@ -450,11 +450,13 @@ def test_task_state_snapshot_restores_bit_identical_rollouts(po, n, mapping):
     env.close(); twin.close(); other.close()
 
 
-@pytest.mark.parametrize("po,n,steps", [(False, 300, 130), (True, 300, 130), (False, 4096, 40), (True, 4090, 40), (True, 37, 60)])
+@pytest.mark.parametrize("po,n,steps", [(False, 300, 130), (True, 300, 130), (False, 4096, 40), (True, 4090, 40), (True, 37, 60),
+                                        (False, 5001, 130), (False, 16384, 35)])
 def test_helper_waves_equal_the_one_role_kernel(po, n, steps, monkeypatch):
-    """qg_step_kernel_link<WALK, .., HELP>: four helper waves per workgroup run the estimator update (and the observation pack's history
-    copy, frame and rows) beside the physics waves.  The two forms (helpers: the default up to 4096 envs; QG_LINK_HELPERS=0 when the
-    simulator is created: the one-role kernel) are different instantiations of the physics, whose contraction choices differ in an ulp
+    """qg_step_kernel_link<WALK, .., HELP> (up to 4096 envs) and qg_step_kernel_quad<2, .., HELP> (walking without the observation pack,
+    4097 .. 16 384 envs: 5001 and 16 384 here): four helper waves per workgroup run the estimator update (and, in the link kernel, the
+    observation pack's history copy, frame and rows) beside the physics waves.  The two forms (helpers: the default; QG_LINK_HELPERS=0
+    when the simulator is created: the one-role kernel) are different instantiations of the physics, whose contraction choices differ in an ulp
     here and there, and this robot's contacts amplify an ulp by 1e4 per env-step -- so the comparison is per STEP from IDENTICAL state:
     before every step the one-role env is restored from the helper env's snapshot.  What does not pass through the physics must then
     agree to the BIT: the estimator's estimates (they read data.ctrl), the commands, the dones, every frame of the 260-value stack but
