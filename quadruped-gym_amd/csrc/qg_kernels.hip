@@ -1164,9 +1164,11 @@ DEV void po_wave_epilogue(const KPoLaunch &PK, const KWalkLaunch &WK, const KSte
 // see qg_step_kernel_pair); the waves of a workgroup do not interact.
 // PO (with WALK; round 3): the partially observable observation pack fused in as in qg_step_kernel_pair<.., PO> (history copy on the
 // substep loop, frame by the env's lead lane, new frames written by the wave); the register-capped development variants (WPE > 2) have none.
-// HELP (with WALK, two-waves-per-SIMD register budget, no observation pack): as in qg_step_kernel_link<.., HELP> -- WAVES more waves
-// per workgroup run the estimator update of their partner wave's channels while that wave goes straight into the substep loop; for
-// grids of at most one physics wave per SIMD (<= 16 384 envs), where the partner's issue slots are otherwise idle.
+// HELP (with WALK, two-waves-per-SIMD register budget): as in qg_step_kernel_link<.., HELP> -- WAVES more waves per workgroup run the
+// estimator update of their partner wave's channels while that wave goes straight into the substep loop; for grids of at most one
+// physics wave per SIMD (<= 16 384 envs), where the partner's issue slots are otherwise idle.  Not with the observation pack: its
+// one-wave-per-SIMD form parks the history copy in AGPRs across each substep, which this register budget has not -- measured 46.9
+// against 48.6 us per step at 16 384 envs (frame_skip 10) in favour of the one-role kernel.
 template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1, bool PO = false, bool HELP = false>
 __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
                                                                              const typename WalkArgT<WALK>::type WK,
