@@ -340,7 +340,8 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else if (wpe == 1) {
             // at most one physics wave per SIMD: helper waves beside them (QG_LINK_HELPERS, as for the one-link-per-lane kernel)
-            if (s->link_helpers && !s->quad_wpe)
+            // (not in the QG_PO_UNFUSED reference mode: its walking launch stays the instantiation the fused observation-pack kernel shares)
+            if (s->link_helpers && !s->quad_wpe && !s->po_unfused)
                 hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, false, true>), g4, dim3(QGK_WAVE * 8), 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
