@@ -11,6 +11,7 @@ tools/profile_gpu.sh r03_pair_n32768_yaw --envs-per-gpu 32768 --random-yaw
 tools/profile_gpu.sh r03_link_n4096_fs20_imu --frame-skip 20 --obs-mode 1
 tools/profile_gpu.sh r03_walking_n4096 --walking
 tools/profile_gpu.sh r03_quad_n4096 --mapping quad
+tools/profile_gpu.sh r03_pair_n262144_yaw --envs-per-gpu 262144 --random-yaw --steps 100
 bash tools/r03_collect.sh profiles-only
 python bench.py > gpurun_out/r03/bench_cfg2.json 2> gpurun_out/r03/bench_cfg2.err; echo "cfg2 rc=$?"
 python bench.py --steps 2000 --warmup 200 --no-cpu-baseline > gpurun_out/r03/bench_cfg2_long.json 2>/dev/null; echo "cfg2 long rc=$?"
