@@ -427,6 +427,8 @@ def main():
         build_id = _abi.load_library().qg_build_id().decode()
         try:
             key = f"{MAP_KEY[sim.mapping]}_n{n}_fs{args.frame_skip}_obs{od}"
+            # the walking layer and the table-driven kernels are other kernels with other traffic: their own entries, or none
+            key += ("_walking" if args.walking else "") + ("" if sim.baked else "_generic")
             with open(os.path.join(ROOT, "profiles", "traffic_index.json")) as fh:
                 idx = json.load(fh)
             ent = idx.get(key)
@@ -439,7 +441,7 @@ def main():
                 stale = prof_id != build_id
             # counted FP32 flops per env-step (SQ_INSTS_VALU_FLOPS_FP32 of the step kernel / envs; FMA = 2): a property of the
             # kernel's instruction stream per substep, so the entry of the same mapping and frame_skip serves every batch size
-            fkey = f"flops_{MAP_KEY[sim.mapping]}_fs{args.frame_skip}"
+            fkey = f"flops_{MAP_KEY[sim.mapping]}_fs{args.frame_skip}" + ("_walking" if args.walking else "") + ("" if sim.baked else "_generic")
             flops = idx.get(fkey)
             if flops is not None and flops.get("build_id") != build_id:
                 stale = True

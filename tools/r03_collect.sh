@@ -13,3 +13,4 @@ python tools/update_traffic_index.py profiles/r03/quad_n4096_pmc.json quad 4096 
 python tools/update_traffic_index.py profiles/r03/pair_n32768_yaw_pmc.json pair 32768 4 33 --flops
 python tools/update_traffic_index.py profiles/r03/link_n4096_fs20_imu_pmc.json link 4096 20 21 --flops
 [ -f profiles/r03/pair_n262144_yaw_pmc.json ] && python tools/update_traffic_index.py profiles/r03/pair_n262144_yaw_pmc.json pair 262144 4 33
+python tools/update_traffic_index.py profiles/r03/walking_n4096_pmc.json link 4096 4 33 --flops --suffix walking

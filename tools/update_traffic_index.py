@@ -3,7 +3,7 @@
 bench.py reads for roofline.traffic / valu_issue / fp32 -- stamped with the build id (hash of the library's sources) the profile
 was taken on, so that bench.py can tell a stale entry (roofline.profile_stale).
 
-usage: update_traffic_index.py <pmc.json> <mapping> <n_envs> <frame_skip> <obs_dim> [--flops]
+usage: update_traffic_index.py <pmc.json> <mapping> <n_envs> <frame_skip> <obs_dim> [--flops] [--suffix walking|generic]
 """
 import json
 import os
@@ -27,15 +27,18 @@ def main():
                           "KiB -> bytes; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B)")
     else:
         ent["method"] = "rocprofv3 --pmc SQ_* pass of bench.py; HBM counters not collected at this size"
-    idx[f"{mapping}_n{n}_fs{fs}_obs{od}"] = ent
+    suffix = ""
+    if "--suffix" in sys.argv:
+        suffix = "_" + sys.argv[sys.argv.index("--suffix") + 1]
+    idx[f"{mapping}_n{n}_fs{fs}_obs{od}{suffix}"] = ent
     if "--flops" in sys.argv and "fp32" in prof:
         flops = prof["fp32"]["SQ_INSTS_VALU_FLOPS_FP32"] * 64.0 / n
-        idx[f"flops_{mapping}_fs{fs}"] = {
+        idx[f"flops_{mapping}_fs{fs}{suffix}"] = {
             "flops_per_env_step": flops, "source": rel, "build_id": bid,
             "method": "SQ_INSTS_VALU_FLOPS_FP32 (= 2*FMA + ADD + MUL + TRANS wave-instructions, checked against the per-class counters) "
                       "x 64 lanes / envs; EVERY lane is counted, so work the mapping replicates across lanes is included"}
     json.dump(idx, open(path, "w"), indent=1)
-    print("updated", f"{mapping}_n{n}_fs{fs}_obs{od}", "build", bid)
+    print("updated", f"{mapping}_n{n}_fs{fs}_obs{od}{suffix}", "build", bid)
 
 
 if __name__ == "__main__":
