@@ -333,6 +333,8 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
         if (po) {                                   // po_fusable(): four-wave workgroups, register cap for one or two waves per SIMD
             if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
+            else if (wpe == 1 && s->link_helpers && !s->quad_wpe)
+                hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, true, true>), g4, dim3(QGK_WAVE * 8), 0, stream, s->d_model, s->d_task, P, *walk, *po);
             else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
             else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
         } else if (!s->baked) {
@@ -340,8 +342,7 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else if (wpe == 1) {
             // at most one physics wave per SIMD: helper waves beside them (QG_LINK_HELPERS, as for the one-link-per-lane kernel)
-            // (not in the QG_PO_UNFUSED reference mode: its walking launch stays the instantiation the fused observation-pack kernel shares)
-            if (s->link_helpers && !s->quad_wpe && !s->po_unfused)
+            if (s->link_helpers && !s->quad_wpe)
                 hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, false, true>), g4, dim3(QGK_WAVE * 8), 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});

@@ -1166,16 +1166,18 @@ DEV void po_wave_epilogue(const KPoLaunch &PK, const KWalkLaunch &WK, const KSte
 // substep loop, frame by the env's lead lane, new frames written by the wave); the register-capped development variants (WPE > 2) have none.
 // HELP (with WALK, two-waves-per-SIMD register budget): as in qg_step_kernel_link<.., HELP> -- WAVES more waves per workgroup run the
 // estimator update of their partner wave's channels while that wave goes straight into the substep loop; for grids of at most one
-// physics wave per SIMD (<= 16 384 envs), where the partner's issue slots are otherwise idle.  Not with the observation pack: its
-// one-wave-per-SIMD form parks the history copy in AGPRs across each substep, which this register budget has not -- measured 46.9
-// against 48.6 us per step at 16 384 envs (frame_skip 10) in favour of the one-role kernel.
+// physics wave per SIMD (<= 16 384 envs), where the partner's issue slots are otherwise idle.  With the observation pack the helper also
+// copies the history rows ring -> out (po_copy_history_now), so that nothing of the copy rides on the physics wave's substep loop: the
+// first version, which kept the in-loop copy with the physics wave, lost to the one-role kernel (48.6 against 46.9 us per step at
+// 16 384 envs, frame_skip 10: at this register budget the copy cannot park in AGPRs across a substep); this one measures 45.4.
 template <int WPE, bool BAKED, bool WALK = false, int WAVES = 1, bool PO = false, bool HELP = false>
 __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_step_kernel_quad(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P,
                                                                              const typename WalkArgT<WALK>::type WK,
                                                                              const typename PoArgT<PO>::type PK) {
     static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
     static_assert(!(PO && WPE > 2), "no fused observation pack in the register-capped development variants");
-    static_assert(!HELP || (WALK && !PO && WPE == 2), "helper waves: walking without the observation pack, two waves per SIMD");
+    static_assert(!HELP || (WALK && WPE == 2), "helper waves: the walking forms at the two-waves-per-SIMD register budget");
+    constexpr bool PO_COPY = PO && !HELP;          // HELP: the helper wave copies the history rows, nothing of it rides on the substep loop
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
     __shared__ float s_est[HELP ? WAVES : 1][QGK_WAVE][6];      // HELP: (f_est, a_est) of the lane's three channels, helper -> physics wave
@@ -1213,6 +1215,11 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
             if (live) walk_estimator_finish_n<3>(WK.P, WK.S, n, ht, hx, hcalls, hw, hf, ha);    // math_utils.py:53-131
 #pragma unroll
             for (int i = 0; i < 3; ++i) { s_est[wave][lane][i] = hf[i]; s_est[wave][lane][3 + i] = ha[i]; }
+            if constexpr (PO) {
+                int slot = PK.S.head[env] + 1;                     // the ring slot the NEW frame will take
+                if (slot >= PK.P.window) slot = 0;
+                if (PK.P.window > 1) po_copy_history_now<4>(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, k, PK.out, live);
+            }
             __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
             return;
         }
@@ -1284,7 +1291,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
         po_ring = po_uniform_addr(PK.S.stack + 2 * po_block);
         po_out = po_uniform_addr(PK.out + po_block);
         if (k == 0) pin = po_env_load(PK.S, n, env);
-        po_row_copy_init<4>(PK.P, el_c, PK.S.head[env], k, pcs);
+        if constexpr (PO_COPY) po_row_copy_init<4>(PK.P, el_c, PK.S.head[env], k, pcs);
     }
     if constexpr (WALK) {
         // every state value is in its register before the first store of the task layer is issued: the waits for those loads
@@ -1329,12 +1336,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
 #pragma unroll 1
         for (int s = 0; s < fs; ++s) {
             PoCopyRegs<PO ? QG_PO_COPY_K : 1> pcr;
-            if constexpr (PO) po_row_copy_load<QG_PO_COPY_K, 4>(PK.P, po_ring, k, s == 0, pcs, pcr);
-            if constexpr (PO && !PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(PK.P, po_out, live, k, s == 0, pcs, pcr);
+            if constexpr (PO_COPY) po_row_copy_load<QG_PO_COPY_K, 4>(PK.P, po_ring, k, s == 0, pcs, pcr);
+            if constexpr (PO_COPY && !PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(PK.P, po_out, live, k, s == 0, pcs, pcr);
             substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, lag && (s == fs - 1), srow, k, zaxis_z);
             if constexpr (PO_DEFER) po_row_copy_store<QG_PO_COPY_K, 4>(PK.P, po_out, live, k, s == 0, pcs, pcr);
         }
-        if constexpr (PO) po_row_copy_rest<QG_PO_COPY_K, 4>(PK.P, po_ring, po_out, live, k, pcs);
+        if constexpr (PO_COPY) po_row_copy_rest<QG_PO_COPY_K, 4>(PK.P, po_ring, po_out, live, k, pcs);
         // the epilogue's addresses are derived from (env, leg) AFTER the loop: visible, they are computed before it and carried through
         // it (see the register-capped variants below; with two waves per SIMD that was 60 bytes of scratch in the walking variant)
         if constexpr (WPE > 1 || !BAKED) asm volatile("" : "+v"(env_e), "+v"(k_e));

@@ -288,6 +288,29 @@ __device__ __forceinline__ void po_copy_history_load(const KPoParams &P, const K
     if ((wbytes & 8) && l16 == 15 && live)                                  // odd windows: the row's last 8 bytes
         *reinterpret_cast<PoF2 *>(dst + wbytes - 8) = *reinterpret_cast<const PoF2 *>(src + wbytes - 8);
 }
+// The whole copy at once, LPE lanes per env (the helper waves of qg_step_kernel_quad<.., PO, HELP>: four lanes per env, batches of
+// four 16-byte groups per lane; they have the whole physics to finish in)
+template <int LPE>
+__device__ __forceinline__ void po_copy_history_now(const KPoParams &P, const KPoState &S, size_t row, int slot, int j, float *__restrict__ out, bool live) {
+    const int wbytes = P.window * QG_PO_FRAME * 4;
+    const char *src = po_hist_src(P, S, row, slot);
+    char *dst = reinterpret_cast<char *>(out + row);
+    const int groups = wbytes >> 4;
+#pragma unroll 1
+    for (int g0 = j; g0 < groups; g0 += 4 * LPE) {
+        PoF4 v[4];
+        int gg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            gg[u] = min(g0 + LPE * u, groups - 1);
+            v[u] = *reinterpret_cast<const PoF4 *>(src + 16 * gg[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (live) *reinterpret_cast<PoF4 *>(dst + 16 * gg[u]) = v[u];
+    }
+    if ((wbytes & 8) && j == LPE - 1 && live)                               // odd windows: the row's last 8 bytes
+        *reinterpret_cast<PoF2 *>(dst + wbytes - 8) = *reinterpret_cast<const PoF2 *>(src + wbytes - 8);
+}
 // after the substep loop and BEFORE po_emit_new (same wave, program order: the new frame then lands on the row's tail, and an env
 // that finished overwrites the whole row)
 __device__ __forceinline__ void po_copy_history_store(const KPoParams &P, size_t row, int l16, float *__restrict__ out, bool live,

@@ -451,10 +451,10 @@ def test_task_state_snapshot_restores_bit_identical_rollouts(po, n, mapping):
 
 
 @pytest.mark.parametrize("po,n,steps", [(False, 300, 130), (True, 300, 130), (False, 4096, 40), (True, 4090, 40), (True, 37, 60),
-                                        (False, 5001, 130), (False, 16384, 35)])
+                                        (False, 5001, 130), (False, 16384, 35), (True, 5001, 60), (True, 16384, 32)])
 def test_helper_waves_equal_the_one_role_kernel(po, n, steps, monkeypatch):
-    """qg_step_kernel_link<WALK, .., HELP> (up to 4096 envs) and qg_step_kernel_quad<2, .., HELP> (walking without the observation pack,
-    4097 .. 16 384 envs: 5001 and 16 384 here): four helper waves per workgroup run the estimator update (and, in the link kernel, the
+    """qg_step_kernel_link<WALK, .., HELP> (up to 4096 envs) and qg_step_kernel_quad<2, .., HELP> (4097 .. 16 384 envs: 5001 and
+    16 384 here, with and without the observation pack): four helper waves per workgroup run the estimator update (and, in the link kernel, the
     observation pack's history copy, frame and rows) beside the physics waves.  The two forms (helpers: the default; QG_LINK_HELPERS=0
     when the simulator is created: the one-role kernel) are different instantiations of the physics, whose contraction choices differ in an ulp
     here and there, and this robot's contacts amplify an ulp by 1e4 per env-step -- so the comparison is per STEP from IDENTICAL state:
