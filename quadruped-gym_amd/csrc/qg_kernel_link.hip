@@ -421,7 +421,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
     const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
 
+    constexpr bool RWDH = HELP && !PO;            // walking without the observation pack: the helper wave also evaluates the reward
     __shared__ float s_est[HELP ? QGK_LINK_WAVES : 1][QGK_WAVE][2];      // HELP: (f_est, a_est) of the lane's channel, helper -> physics wave
+    __shared__ float s_done[RWDH ? QGK_LINK_WAVES : 1][QGK_LINK_ENVS];   // RWDH: the step's termination flags, physics -> helper
     __shared__ float s_new[PO ? QG_PO_ENVS : 1][QG_PO_FRAME];     // PO: the frame of this step
     __shared__ float s_rst[PO ? QG_PO_ENVS : 1][QG_PO_FRAME];     // PO: the frame reset() would return (only for envs that finished)
     __shared__ int s_slot[PO ? QG_PO_ENVS : 1], s_fin[PO ? QG_PO_ENVS : 1];
@@ -431,6 +433,22 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
             const int rk = r < 3 ? r : 2, jch = 3 * k + rk;
             const int tt[1] = {env * 12 + jch};
             float wf[1] = {0.f}, wa[1] = {0.f};
+            // RWDH: what the reward needs and does not come out of the physics -- the env-clipped action (settling mask included), the
+            // previous control, the channel's targets, the env's task state -- loaded now, ahead of the estimator's stores
+            float h_aclip = 0.f, h_wprev = 0.f;
+            WalkChanTargets h_wtg = {0.f, 0.f, 0.f};
+            WalkEnvIn hwin = {};
+            if constexpr (RWDH) {
+                h_wtg = walk_channel_targets(WK.P, jch);
+                float a_in = P.actions[(size_t)env * 12 + jch];
+                if (P.st.nstep[env] < WK.P.settle_substeps) a_in = h_wtg.center;      // data.time < settling_time (walking_quad.py:142-143)
+                h_aclip = fminf(fmaxf(a_in, -1.f), 1.f);                                // quadruped.py:160
+                if (r < 3) h_wprev = WK.S.prev_ctrl[tt[0]];
+                if (lead_env) {
+                    hwin = walk_env_load(WK.S, n, env);
+                    hwin.episode_key = P.st.episode[env];     // not advanced yet: the physics wave does that behind the barrier
+                }
+            }
             if (r < 3) {
                 const int calls = WK.S.calls[env];
                 const float xx[1] = {P.st.ctrl[jch * n + env]};       // data.ctrl of the PREVIOUS step (walking_quad.py:136)
@@ -438,8 +456,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
                 walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west, live);
                 if (live) walk_estimator_finish_n<1>(WK.P, WK.S, n, tt, xx, calls, west, wf, wa);    // math_utils.py:53-131
             }
-            s_est[wave][lane][0] = wf[0];
-            s_est[wave][lane][1] = wa[0];
+            if constexpr (!RWDH) {
+                s_est[wave][lane][0] = wf[0];
+                s_est[wave][lane][1] = wa[0];
+            }
             if constexpr (PO) {
                 const PoEnvIn pin0 = po_env_load(PK.S, n, env);
                 int slot = pin0.head + 1;
@@ -468,7 +488,20 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
                 po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
                 return;
             }
-            __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
+            __syncthreads();      // the one barrier of the workgroup: behind it the physics waves write what this wave read at entry
+            if constexpr (RWDH) {
+                // the reward of the step, on the sensor tile the physics wave has finished (LDS), while that wave stores the state
+                // and writes the observation rows
+                const bool hdone = s_done[wave][el] != 0.f;
+                WalkSums sum = {0.f, 0.f, 0.f, 0.f};
+                if (live && r < 3) {
+                    walk_channel_terms(WK.S, env, jch, h_wtg, h_aclip, h_wprev, wf[0], wa[0], sum);
+                    WK.S.prev_ctrl[tt[0]] = h_aclip;
+                }
+                sum.cost = env_sum(sum.cost); sum.posture = env_sum(sum.posture); sum.amp = env_sum(sum.amp); sum.frq = env_sum(sum.frq);
+                if (live && lead_env)
+                    walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, hwin, hdone, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
+            }
             return;
         }
     }
@@ -545,13 +578,13 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         if constexpr (!HELP) calls = WK.S.calls[env];
         wtg = walk_channel_targets(WK.P, jch);
         if (r < 3) {
-            wprev = WK.S.prev_ctrl[tt[0]];            // previous_ctrl of the control cost (:260-262)
+            if constexpr (!RWDH) wprev = WK.S.prev_ctrl[tt[0]];            // previous_ctrl of the control cost (:260-262)
             if constexpr (!HELP) {
                 xx[0] = P.st.ctrl[jch * n + env];     // data.ctrl of the PREVIOUS step: what the estimator takes (walking_quad.py:136)
                 walk_estimator_load_n<1>(WK.P, WK.S, n, tt, calls, west, live);
             }
         }
-        if (lead_env) {
+        if (!RWDH && lead_env) {
             win = walk_env_load(WK.S, n, env);
             win.episode_key = P.st.episode[env];      // not advanced yet: the key of the episode that begins if this one ends
         }
@@ -647,9 +680,17 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         // the helper wave of this SIMD finished its first job long ago (its estimator stores and history copy have landed: the barrier's
         // wait covers them); from here on this wave may overwrite what the helper read at entry (data.ctrl, the task state), and the
         // helper builds the observation pack's frame from the sensor tile, which nothing changes any more
+        if constexpr (RWDH) {
+            if (lead_env) {
+                s_done[wave][el] = done ? 1.f : 0.f;
+                if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // (the tile is final before the helper reads it)
+            }
+        }
         __syncthreads();
-        wf[0] = s_est[wave][lane][0];
-        wa[0] = s_est[wave][lane][1];
+        if constexpr (!RWDH) {
+            wf[0] = s_est[wave][lane][0];
+            wa[0] = s_est[wave][lane][1];
+        }
     }
     if (lead) {
         lk_st(P.st.qpos, e4, B.pw.x); lk_st(P.st.qpos, n4 + e4, B.pw.y); lk_st(P.st.qpos, 2 * n4 + e4, B.pw.z);
@@ -668,7 +709,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         if (P.track_ctrl) lk_st(P.st.ctrl, j4, rst ? Tk.default_ctrl[jch] : aclip);
     }
     if (lead_env) {
-        if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
+        if (!RWDH && od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // IMU pack: velocimeter follows the gyro
         if (P.packed) { srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f; }
     }
     wave_sync();                                                    // the tile is this wave's own
@@ -697,7 +738,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         if constexpr (!WALK) P.reward[env] = reward;
         P.done[env] = done ? 1 : 0;
     }
-    if constexpr (WALK) {
+    if constexpr (WALK && !RWDH) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
         if (wch) {
             walk_channel_terms(WK.S, env, jch, wtg, aclip, wprev, wf[0], wa[0], sum);
