@@ -1180,7 +1180,9 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     constexpr bool PO_COPY = PO && !HELP;          // HELP: the helper wave copies the history rows, nothing of it rides on the substep loop
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
+    constexpr bool RWDH = HELP && !PO;              // walking without the observation pack: the helper wave also evaluates the reward
     __shared__ float s_est[HELP ? WAVES : 1][QGK_WAVE][6];      // HELP: (f_est, a_est) of the lane's three channels, helper -> physics wave
+    __shared__ float s_done[RWDH ? WAVES : 1][QGK_QUAD_ENVS];   // RWDH: the step's termination flags, physics -> helper
     const int lane = threadIdx.x & (QGK_WAVE - 1);
     const int wave = HELP ? ((threadIdx.x >> 6) % WAVES) : (threadIdx.x >> 6);      // HELP: waves WAVES .. 2 WAVES - 1 shadow waves 0 .. WAVES - 1
     const bool helper = HELP && (int)(threadIdx.x >> 6) >= WAVES;
@@ -1208,6 +1210,25 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
             const int ht[3] = {env * 12 + 3 * k + 0, env * 12 + 3 * k + 1, env * 12 + 3 * k + 2};
             const int hcalls = WK.S.calls[env];
             float hx[3], hf[3] = {0.f, 0.f, 0.f}, ha[3] = {0.f, 0.f, 0.f};
+            // RWDH: what the reward needs and does not come out of the physics, loaded ahead of the estimator's stores
+            float h_aclip[3] = {0.f, 0.f, 0.f}, h_wprev[3] = {0.f, 0.f, 0.f};
+            WalkChanTargets h_wtg[3] = {};
+            WalkEnvIn hwin = {};
+            if constexpr (RWDH) {
+                const bool hsettle = P.st.nstep[env] < WK.P.settle_substeps;        // data.time < settling_time (walking_quad.py:142-143)
+                walk_ldv<3>(WK.S.prev_ctrl + ht[0], h_wprev);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    h_wtg[i] = walk_channel_targets(WK.P, 3 * k + i);
+                    float a_in = P.actions[(size_t)env * 12 + 3 * k + i];
+                    if (hsettle) a_in = WK.P.joint_centers[3 * k + i];
+                    h_aclip[i] = fminf(fmaxf(a_in, -1.f), 1.f);                      // quadruped.py:160
+                }
+                if (k == 0) {
+                    hwin = walk_env_load(WK.S, n, env);
+                    hwin.episode_key = P.st.episode[env];      // not advanced yet: the physics wave does that behind the barrier
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) hx[i] = P.st.ctrl[(3 * k + i) * n + env];   // data.ctrl of the PREVIOUS step (walking_quad.py:136)
             WalkEstIn<3> hw;
@@ -1221,6 +1242,20 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
                 if (PK.P.window > 1) po_copy_history_now<4>(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, k, PK.out, live);
             }
             __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
+            if constexpr (RWDH) {
+                // the reward of the step, on the sensor tile the physics wave has finished (LDS), while that wave goes on with the resets and
+                // the state stores
+                const bool hdone = s_done[wave][el] != 0.f;
+                WalkSums sum = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) walk_channel_terms(WK.S, env, 3 * k + i, h_wtg[i], h_aclip[i], h_wprev[i], hf[i], ha[i], sum);
+                    walk_stv<3>(WK.S.prev_ctrl + (size_t)env * 12 + 3 * k, h_aclip);                         // previous_ctrl moves on (:260-262)
+                }
+                sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
+                if (live && k == 0)
+                    walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, hwin, hdone, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
+            }
             return;
         }
     }
@@ -1442,30 +1477,34 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
 #pragma unroll                        // instead of carrying 21 values through the substep loop
             for (int i = 0; i < 3; ++i) {
                 const int t = env_e * 12 + 3 * k_e + i;
-                wprev[i] = WK.S.prev_ctrl[t];
+                if constexpr (!RWDH) wprev[i] = WK.S.prev_ctrl[t];
                 if constexpr (!HELP) { wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t]; }
-                wtg[i] = walk_channel_targets(WK.P, 3 * k_e + i);
+                if constexpr (!RWDH) wtg[i] = walk_channel_targets(WK.P, 3 * k_e + i);
             }
-            if (lead) {
+            if (!RWDH && lead) {
                 win = walk_env_load(WK.S, n, env_e);
                 win.episode_key = P.st.episode[env_e];
             }
         }
         if constexpr (HELP) {
-            // the helper wave of this SIMD finished long ago (its estimator stores have landed: the barrier's wait covers them); from
-            // here on this wave may overwrite what the helper read at entry (data.ctrl)
+            // the helper wave of this SIMD finished its first job long ago (its estimator stores have landed: the barrier's wait covers
+            // them); from here on this wave may overwrite what the helper read at entry (data.ctrl, the episode counter), and (RWDH)
+            // the helper evaluates the reward on the finished sensor tile
+            if constexpr (RWDH) { if (k_e == 0) s_done[wave][lane >> 2] = done ? 1.f : 0.f; }
             __syncthreads();
+            if constexpr (!RWDH) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { wf[i] = s_est[wave][lane][i]; wa[i] = s_est[wave][lane][3 + i]; }
+                for (int i = 0; i < 3; ++i) { wf[i] = s_est[wave][lane][i]; wa[i] = s_est[wave][lane][3 + i]; }
+            }
         }
-        if (live) {
+        if (!RWDH && live) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) walk_channel_terms(WK.S, env_e, 3 * k_e + i, wtg[i], aclip[i], wprev[i], wf[i], wa[i], sum);
             walk_stv<3>(WK.S.prev_ctrl + (size_t)env_e * 12 + 3 * k_e, aclip);                       // previous_ctrl moves on (:260-262)
         }
-        sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
+        if constexpr (!RWDH) { sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq); }
         QG_MARK(4);                                  // channel terms + sums
-        if (lead) walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
+        if (!RWDH && lead) walk_reward_env(WK.P, WK.S, n, env_e, tile + (lane >> 2) * 35, sum, win, done, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
     }
     if (lead && P.comps) {
         P.comps[(size_t)env_e * 3 + 0] = c_fwd;
