@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     constexpr bool PO_COPY = PO && !HELP;          // HELP: the helper wave copies the history rows, nothing of it rides on the substep loop
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
-    constexpr bool RWDH = HELP && !PO;              // walking without the observation pack: the helper wave also evaluates the reward
+    constexpr bool RWDH = HELP;                     // the helper wave also evaluates the reward (the physics wave keeps the observation pack's frame)
     __shared__ float s_est[HELP ? WAVES : 1][QGK_WAVE][6];      // HELP: (f_est, a_est) of the lane's three channels, helper -> physics wave
     __shared__ float s_done[RWDH ? WAVES : 1][QGK_QUAD_ENVS];   // RWDH: the step's termination flags, physics -> helper
     const int lane = threadIdx.x & (QGK_WAVE - 1);
@@ -1481,7 +1481,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
                 if constexpr (!HELP) { wf[i] = WK.S.f_est[t]; wa[i] = WK.S.a_est[t]; }
                 if constexpr (!RWDH) wtg[i] = walk_channel_targets(WK.P, 3 * k_e + i);
             }
-            if (!RWDH && lead) {
+            if ((!RWDH || PO) && lead) {
                 win = walk_env_load(WK.S, n, env_e);
                 win.episode_key = P.st.episode[env_e];
             }
