@@ -39,6 +39,12 @@ PATTERNS = [
     ("add_dpp quad_perm, EXEC = lanes 0-31", "v_add_f32_dpp v{d}, v{a}, v{b} quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", [(8 + i, 13 + i, 0) for i in range(8)], "0xffffffff"),
     ("fmac  EXEC = lanes 0-15", "v_fmac_f32_e32 v{d}, v{a}, v{b}", [(9 + i, 14 + i, 0) for i in range(8)], "0xffff"),
     ("fmac  EXEC = lanes 0-15 and 32-47", "v_fmac_f32_e32 v{d}, v{a}, v{b}", [(9 + i, 14 + i, 0) for i in range(8)], "0x0000ffff0000ffff"),
+    # dependent chains (dst = src0): round 2's "two interleaved chains" ran at 4.0-4.4 cycles per SIMD slot at every occupancy
+    ("fma   2 chains dst=src0, shared b,c", "v_fma_f32 v{d}, v{d}, v{b}, v{c}", [(0, 8, 13)] * 8, None, [40, 41] * 4),
+    ("fma   2 chains dst=src0, own b,c", "v_fma_f32 v{d}, v{d}, v{b}, v{c}", [(0, 8, 13), (0, 10, 15)] * 4, None, [40, 41] * 4),
+    ("fma   4 chains dst=src0, shared b,c", "v_fma_f32 v{d}, v{d}, v{b}, v{c}", [(0, 8, 13)] * 8, None, [40, 41, 42, 43] * 2),
+    ("fma   8 chains dst=src0, shared b,c", "v_fma_f32 v{d}, v{d}, v{b}, v{c}", [(0, 8, 13)] * 8, None, [40, 41, 42, 43, 44, 45, 46, 47]),
+    ("fmac  2 chains, shared a,b", "v_fmac_f32_e32 v{d}, v{a}, v{b}", [(8, 13, 0)] * 8, None, [40, 41] * 4),
     ("pk_mul pairs (0,1)(0,1)", "v_pk_mul_f32 v[{d}:{d1}], v[{a}:{a1}], v[{b}:{b1}]", [(8 + 4 * (i % 2), 16 + 4 * (i % 2), 0) for i in range(8)]),
 ]
 
@@ -78,13 +84,14 @@ def main():
     for idx, pat in enumerate(PATTERNS):
         name, tmpl, srcs = pat[:3]
         execmask = pat[3] if len(pat) > 3 else None
+        dsts = pat[4] if len(pat) > 4 else None
         init = "\n".join('        "v_mov_b32 v%d, 1.0\\n\\t"' % r for r in range(8, 48))
         body = []
         for rep in range(8):
             for i in range(8):
                 a, b, c = srcs[i]
                 pk = "pk_" in tmpl
-                d = 40 + (2 * (i % 4) if pk else i)
+                d = dsts[i] if dsts else 40 + (2 * (i % 4) if pk else i)
                 body.append('        "' + tmpl.format(d=d, d1=d + 1, a=a, a1=a + 1, b=b, b1=b + 1, c=c, c1=c + 1) + '\\n\\t"')
         clob = ", ".join('"v%d"' % r for r in range(8, 48))
         execset = ""
