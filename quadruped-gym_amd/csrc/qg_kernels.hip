@@ -1180,9 +1180,11 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     constexpr bool PO_COPY = PO && !HELP;          // HELP: the helper wave copies the history rows, nothing of it rides on the substep loop
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
     __shared__ KModel smodel;                       // generic variant: the link / joint tables staged in LDS (3.2 KB)
-    constexpr bool RWDH = HELP;                     // the helper wave also evaluates the reward (the physics wave keeps the observation pack's frame)
+    constexpr bool RWDH = HELP && !PO;              // walking without the observation pack: the helper wave also evaluates the reward
+    constexpr bool POH = HELP && PO;                // with it: the helper wave builds the new frame and writes the rows, the reward stays here
     __shared__ float s_est[HELP ? WAVES : 1][QGK_WAVE][6];      // HELP: (f_est, a_est) of the lane's three channels, helper -> physics wave
-    __shared__ float s_done[RWDH ? WAVES : 1][QGK_QUAD_ENVS];   // RWDH: the step's termination flags, physics -> helper
+    __shared__ float s_done[HELP ? WAVES : 1][QGK_QUAD_ENVS];   // HELP: the step's termination flags, physics -> helper
+    __shared__ float s_q[POH ? WAVES : 1][QGK_QUAD_ENVS][4];    // POH: data.qpos[3:7] as the step leaves it (after the auto-reset), physics -> helper
     const int lane = threadIdx.x & (QGK_WAVE - 1);
     const int wave = HELP ? ((threadIdx.x >> 6) % WAVES) : (threadIdx.x >> 6);      // HELP: waves WAVES .. 2 WAVES - 1 shadow waves 0 .. WAVES - 1
     const bool helper = HELP && (int)(threadIdx.x >> 6) >= WAVES;
@@ -1214,12 +1216,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
             float h_aclip[3] = {0.f, 0.f, 0.f}, h_wprev[3] = {0.f, 0.f, 0.f};
             WalkChanTargets h_wtg[3] = {};
             WalkEnvIn hwin = {};
-            if constexpr (RWDH) {
+            if constexpr (HELP) {
                 const bool hsettle = P.st.nstep[env] < WK.P.settle_substeps;        // data.time < settling_time (walking_quad.py:142-143)
-                walk_ldv<3>(WK.S.prev_ctrl + ht[0], h_wprev);
+                if constexpr (RWDH) walk_ldv<3>(WK.S.prev_ctrl + ht[0], h_wprev);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    h_wtg[i] = walk_channel_targets(WK.P, 3 * k + i);
+                    if constexpr (RWDH) h_wtg[i] = walk_channel_targets(WK.P, 3 * k + i);
                     float a_in = P.actions[(size_t)env * 12 + 3 * k + i];
                     if (hsettle) a_in = WK.P.joint_centers[3 * k + i];
                     h_aclip[i] = fminf(fmaxf(a_in, -1.f), 1.f);                      // quadruped.py:160
@@ -1255,6 +1257,15 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
                 sum.cost = quad_sum(sum.cost); sum.posture = quad_sum(sum.posture); sum.amp = quad_sum(sum.amp); sum.frq = quad_sum(sum.frq);
                 if (live && k == 0)
                     walk_reward_env(WK.P, WK.S, n, env, tile + el * 35, sum, hwin, hdone, P.reward, WK.comps, WK.sample, P.seed, P.env_index_base);
+            }
+            if constexpr (POH) {
+                // the observation pack's new frame and rows, on the finished sensor tile and the orientation the physics wave handed over,
+                // while that wave evaluates the reward and stores the state
+                BaseState hb = {};
+                hb.qw = s_q[wave][el][0]; hb.qx = s_q[wave][el][1]; hb.qy = s_q[wave][el][2]; hb.qz = s_q[wave][el][3];
+                const int h_live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));
+                po_wave_epilogue<QGK_QUAD_ENVS, 4, WAVES, true>(PK, WK, P, n, env, env0, h_live_envs, wave, lane, el, k, live, live && k == 0, PoEnvIn{},
+                                                                tile + el * 35, hb, hwin, s_done[wave][el] != 0.f, h_aclip);
             }
             return;
         }
@@ -1471,6 +1482,29 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
         if constexpr (!WALK) P.reward[env_e] = reward;
         P.done[env_e] = done ? 1 : 0;
     }
+    bool rst_done = false;
+    if constexpr (POH) {
+        // the auto-reset of the base FIRST (the reward below does not look at B): the helper wave's frame shows data.qpos[3:7] as the step
+        // leaves it
+        if (done && T->auto_reset) {
+            B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+            B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+            if (T->reset_flags & 1u) {
+                float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env_e, (uint64_t)P.st.episode[env_e]);
+                float sn, cs;
+                sincos_f(0.5f * a, sn, cs);
+                B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+            }
+            B.vw = v3(0.f, 0.f, 0.f);
+            B.wb = v3(0.f, 0.f, 0.f);
+            nstep = 0;
+        }
+        rst_done = true;
+        if (k_e == 0) {
+            s_done[wave][lane >> 2] = done ? 1.f : 0.f;
+            s_q[wave][lane >> 2][0] = B.qw; s_q[wave][lane >> 2][1] = B.qx; s_q[wave][lane >> 2][2] = B.qy; s_q[wave][lane >> 2][3] = B.qz;
+        }
+    }
     if constexpr (WALK) {
         WalkSums sum = {0.f, 0.f, 0.f, 0.f};
         if constexpr (WPE > 1) {       // two waves share the SIMD: read the task state again here (the other wave covers the latency)
@@ -1513,7 +1547,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     }
 
     const bool rst = done && T->auto_reset;
-    if (rst) {
+    if (rst && !rst_done) {
         B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
         B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
         if (T->reset_flags & 1u) {
@@ -1544,7 +1578,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
             if (P.track_ctrl) P.st.ctrl[j * n + env_e] = rst ? T->default_ctrl[j] : aclip[i];
         }
     }
-    if constexpr (PO)
+    if constexpr (PO && !POH)
         po_wave_epilogue<QGK_QUAD_ENVS, 4, WAVES, (WPE > 1)>(PK, WK, P, n, env, env0, live_envs, wave, lane, el, k, live, lead, pin, srow, B, win, done, aclip);
 }
 
