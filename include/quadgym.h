@@ -226,6 +226,39 @@ int qg_uses_baked_model(const qg_sim *sim);
 int qg_set_mapping(qg_sim *sim, int32_t mapping);
 int qg_get_mapping(const qg_sim *sim);
 
+/* ---- many env-steps per launch (round 4; one-link-per-lane mapping, <= 4096 envs, packed rows, no task layer) ----------------
+ * The reference keeps an env's state in MjData across steps (quadruped.py:163-165: the hot loop re-reads nothing); the per-launch
+ * step kernel re-loads and stores it around every env-step.  Two forms keep it in registers instead:
+ *
+ * qg_step_device_seq: ONE launch runs `count` env-steps on actions[count][n_envs][12] and writes packed[count][n_envs][obs_dim + 2]
+ * (device pointers, `stream` as for qg_step_device) -- open-loop sequences (action repeat, a planned sequence, K-step graphs).
+ * Results are bit-identical to `count` calls of qg_step_device_packed.
+ *
+ * The RESIDENT form (opt-in): qg_resident_start launches the step kernel once on the library's own stream; it stays on the GPU and
+ * is handed each env-step through a mailbox in device memory -- `slots` action buffers [n_envs][12] and `slots` output buffers
+ * [n_envs][obs_dim + 2] (qg_resident_buffers), env-step i of the resident sequence (counted from qg_resident_start) uses slot
+ * i % slots.  qg_resident_step_device(count, stream) enqueues a RING on the caller's stream: it makes the next `count` env-steps
+ * runnable and holds the stream until their rows are in memory -- a policy on the same stream stays in the loop (read the rows,
+ * write the next slot's actions, ring); `count` > 1 lets the kernel run ahead through slots the caller filled beforehand.
+ * Nothing in it waits without a deadline: a kernel that is not rung for `idle_timeout_us` (0 = 2000; 50 .. 100000) stores the
+ * state and leaves; the next qg_resident_step_device (or qg_resident_ensure, for graph replays) launches it again.  A ring that
+ * meets a retired kernel does NOT run its steps; the next resident call returns QG_ERR_LAUNCH and says how many (the state is that
+ * of the last executed step).  Every entry point that needs the state in memory (reset, get / set_state, set_task, the per-launch
+ * steps, destroy) first retires the kernel; qg_resident_stop retires it and frees the mailbox.
+ * Measured: closed-loop rings cost MORE per env-step than a kernel launch; the form pays for run-ahead only. */
+int qg_step_device_seq(qg_sim *sim, const float *actions, float *packed, int32_t count, void *stream);
+/* actions / packed: the mailbox's slot buffers, [slots][n_envs][12] and [slots][n_envs][obs_dim + 2] f32 in device memory that the
+ * caller owns and keeps alive until qg_resident_stop -- or both NULL: the library allocates them (qg_resident_buffers). */
+int qg_resident_start(qg_sim *sim, int32_t slots, int32_t idle_timeout_us, float *actions, float *packed);
+int qg_resident_stop(qg_sim *sim);
+int qg_resident_buffers(qg_sim *sim, float **actions, float **packed, int32_t *slots);
+int qg_resident_step_device(qg_sim *sim, int32_t count, void *stream);
+/* Launch the resident kernel again if it has retired (idle): call before replaying a hipGraph that holds captured rings. */
+int qg_resident_ensure(qg_sim *sim);
+/* No synchronisation: env-steps rung through the API, whether the kernel is on the GPU, the env-steps completed when it last left,
+ * env-steps of rings that met a retired kernel (cumulative).  Any output may be NULL. */
+int qg_resident_status(qg_sim *sim, int64_t *rung, int32_t *running, int64_t *completed_at_exit, int64_t *not_executed);
+
 /* ---- native per-step exchange over RCCL (opt-in) --------------------------------------------------------------
  * Env batches shard across the GPUs of a node, one process per GPU, no exchange inside the physics; once per env-step
  * the packed [n_envs][obs_dim + 2] rows are gathered to `root` over xGMI.  These entry points issue that gather from C

@@ -211,6 +211,13 @@ def load_library():
     lib.qg_get_reset_streams.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
     lib.qg_set_reset_streams.argtypes = [vp, vp, C.c_uint64]
     lib.qg_po_step_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.qg_step_device_seq.argtypes = [vp, vp, vp, C.c_int32, vp]
+    lib.qg_resident_start.argtypes = [vp, C.c_int32, C.c_int32, vp, vp]
+    lib.qg_resident_stop.argtypes = [vp]
+    lib.qg_resident_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int32)]
+    lib.qg_resident_step_device.argtypes = [vp, C.c_int32, vp]
+    lib.qg_resident_ensure.argtypes = [vp]
+    lib.qg_resident_status.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qg_version", "qg_build_id", "qg_last_error", "qg_time_limit_substeps", "qg_walk_state_bytes", "qg_po_state_bytes"):
@@ -231,6 +238,8 @@ EXPORTS = (
     "qg_po_create", "qg_po_destroy", "qg_po_obs_dim", "qg_po_reset", "qg_po_step", "qg_po_step_device",
     "qg_walk_state_bytes", "qg_walk_get_state", "qg_walk_set_state", "qg_po_state_bytes", "qg_po_get_state", "qg_po_set_state",
     "qg_get_reset_streams", "qg_set_reset_streams",
+    "qg_step_device_seq", "qg_resident_start", "qg_resident_stop", "qg_resident_buffers", "qg_resident_step_device",
+    "qg_resident_ensure", "qg_resident_status",
 )
 
 

@@ -19,6 +19,7 @@
 // the kernels are compiled in the same translation unit (one code object, no -fgpu-rdc)
 #include "qg_kernels.hip"
 #include "qg_kernel_link.hip"
+#include "qg_kernel_resident.hip"
 #include "qg_walk.hip"
 #include "qg_po.hip"
 #include "qg_tables.h"
@@ -52,7 +53,22 @@ struct qg_sim {
     int32_t walk_bound;       // qg_walk layers bound to this handle (qg_set_task refuses while > 0)
     int32_t po_unfused;       // env QG_PO_UNFUSED=1: keep the observation pack of qg_po_step a launch of its own (A/B, parity test)
     int32_t quad_wpe;         // development override of the quad kernel's register cap (waves per SIMD), env QG_QUAD_WPE; 0 = policy
+    // resident form of the one-link-per-lane step (qg_resident_*, qg_kernel_resident.hip)
+    struct {
+        int32_t active;       // qg_resident_start has set the mailbox up (the mode is on until qg_resident_stop)
+        int32_t launched;     // a resident launch has been enqueued and has not been waited for since
+        KResident k;          // mailbox pointers, slots, time-outs
+        void *d_mail;         // door, arrival shards, completed counter (one allocation)
+        volatile unsigned long long *hstat;   // page-locked host words the kernels report into
+        hipStream_t ctl_stream;
+        hipStream_t last_stream;              // where the latest ring went (waited for before the kernel is retired)
+        int32_t own_buffers;                  // the action / output slots are the library's (else the caller's, qg_resident_start)
+        int64_t rung;         // env-steps rung through the API since qg_resident_start
+        uint64_t lost_seen, gaveup_seen;
+    } res;
 };
+static int resident_retire(qg_sim *s);
+static void resident_free(qg_sim *s);
 
 static thread_local char g_err[512] = "";
 
@@ -110,7 +126,9 @@ extern "C" int64_t qg_time_limit_substeps(double timestep, double max_time) { re
 extern "C" int qg_destroy(qg_sim *s) {
     if (!s) return QG_OK;
     (void)hipSetDevice(s->device);
+    (void)resident_retire(s);
     (void)hipDeviceSynchronize();                  // steps may still be in flight on a caller's stream (the header's ordering contract)
+    resident_free(s);
     void *ptrs[] = {s->d_model, s->d_task, s->st.qpos, s->st.qvel, s->st.act, s->st.ctrl, s->st.nstep, s->st.episode, s->d_actions,
                     s->d_obs,   s->d_reward, s->d_comps, s->d_stage, s->d_done, s->d_mask};
     for (void *p : ptrs)
@@ -220,7 +238,8 @@ extern "C" int qg_reset(qg_sim *s, const uint8_t *mask, uint64_t seed, uint32_t 
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     // steps may be in flight on a caller's stream (qg_step_device*): the reset runs on the library's own non-blocking stream
-    // and must not overlap them
+    // and must not overlap them (a resident step kernel first stores the state it holds in registers and leaves)
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     // the seed keys the reset streams of EVERY env (auto-resets included): only a whole-batch reset may change it, a masked
     // reset draws from the streams already in force
@@ -297,6 +316,10 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     P.env_index_base = s->env_index_base;
     int blocks = (s->n + QGK_WAVE - 1) / QGK_WAVE;
     const int emap = effective_mapping(s);
+    if (s->res.launched) {            // a per-launch step while the resident kernel holds the state in registers: it has to hand it back first
+        int rr = resident_retire(s);
+        if (rr != QG_OK) return rr;
+    }
     if (stream != s->stream) {
         s->caller_inflight = 1;
         if (!s->captured_once) {
@@ -447,6 +470,7 @@ static void pin_out_finish(qg_sim *s, const PinOut &o) {
 // The host-pointer steps must not overtake device-pointer steps still in flight on a caller's stream; a device-wide wait is only
 // needed if one has been enqueued since the last one (the library's own stream is synchronised at the end of every host-pointer call).
 static int wait_for_caller_streams(qg_sim *s) {
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     if (!s->caller_inflight && !s->captured_once) return QG_OK;
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     s->caller_inflight = 0;
@@ -518,6 +542,7 @@ static int state_out_enqueue(qg_sim *s, const StateOut &so) {
 extern "C" int qg_get_state(qg_sim *s, float *qpos, float *qvel, float *act, float *ctrl, int32_t *nstep) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps may be in flight on a caller's stream
     // every transfer enqueued, ONE synchronisation (five synchronised round trips made the single-env facade's mirror of the state
     // 120 us of a 160 us step)
@@ -563,6 +588,7 @@ extern "C" int qg_step_mirror(qg_sim *s, const float *actions, float *obs, float
 extern "C" int qg_set_state(qg_sim *s, const float *qpos, const float *qvel, const float *act, const float *ctrl, const int32_t *nstep) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     int rc;
     if ((rc = copy_in(s, qpos, s->st.qpos, QG_NQ)) != QG_OK) return rc;
@@ -576,6 +602,7 @@ extern "C" int qg_set_state(qg_sim *s, const float *qpos, const float *qvel, con
 extern "C" int qg_time_step_kernel(qg_sim *s, const float *d_actions, float *d_packed, int32_t iters, float *ms_per_launch) {
     if (!s || !d_actions || !d_packed || iters < 1 || !ms_per_launch) return fail(QG_ERR_ARG, "qg_time_step_kernel: bad argument");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     // the launches are exactly what qg_step_device_packed enqueues (data.ctrl write-back as the handle has it set)
     HIP_TRY(hipEventRecord(s->ev0, s->stream), QG_ERR_DEVICE);
@@ -597,6 +624,7 @@ extern "C" int qg_set_mapping(qg_sim *s, int32_t mapping) {
         return fail(QG_ERR_ARG, "qg_set_mapping: the two-legs-per-lane kernel serves the compiled-in robot only");
     if (mapping != QG_MAP_AUTO && mapping != QG_MAP_LANE && mapping != QG_MAP_QUAD && mapping != QG_MAP_PAIR && mapping != QG_MAP_LINK)
         return fail(QG_ERR_ARG, "qg_set_mapping: unknown mapping %d", mapping);
+    if (s->res.active) return fail(QG_ERR_ARG, "qg_set_mapping: the resident step mode is on (qg_resident_stop first)");
     s->mapping = mapping;
     return QG_OK;
 }
@@ -614,6 +642,7 @@ extern "C" int qg_set_task(qg_sim *s, const qg_task *task) {
     int rc = build_tables(&s->model, task, &km, &kt);
     if (rc != QG_OK) return rc;
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);   // steps reading the old task may be in flight on a caller's stream
     HIP_TRY(hipMemcpy(s->d_task, &kt, sizeof kt, hipMemcpyHostToDevice), QG_ERR_DEVICE);
     s->task = *task;
@@ -641,7 +670,227 @@ extern "C" int qg_debug_phase_times(uint64_t out[16]) {
 
 extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
+    if ((on ? 1 : 0) != s->track_ctrl) { int rr = resident_retire(s); if (rr != QG_OK) return rr; }      // (a resident launch holds the old setting)
     s->track_ctrl = on ? 1 : 0;
+    return QG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// many env-steps per launch: the sequence form and the resident form of the one-link-per-lane kernel (qg_kernel_resident.hip)
+// ------------------------------------------------------------------------------------------------------
+static int multi_step_usable(const qg_sim *s, const char *who) {
+    if (effective_mapping(s) != QG_MAP_LINK)
+        return fail(QG_ERR_ARG, "%s: needs the one-link-per-lane mapping (AUTO up to 4096 envs, lagged sensors)", who);
+    if (s->n > 1024 * QGK_LINK_ENVS) return fail(QG_ERR_ARG, "%s: at most %d envs (one wave per SIMD)", who, 1024 * QGK_LINK_ENVS);
+    if (s->walk_bound) return fail(QG_ERR_ARG, "%s: a walking task layer is bound to this handle", who);
+    if (s->task.auto_reset && (s->task.reset_flags & QG_RESET_JOINT_JITTER))
+        return fail(QG_ERR_ARG, "%s: hinge jitter at auto-reset is a launch of its own behind every step; not available in this form", who);
+    return QG_OK;
+}
+static KStepArgs multi_step_args(const qg_sim *s) {
+    KStepArgs P = {};
+    P.st = s->st;
+    P.n = s->n;
+    P.track_ctrl = s->track_ctrl;
+    P.seed = s->seed;
+    P.env_index_base = s->env_index_base;
+    return P;
+}
+static dim3 multi_step_grid(const qg_sim *s) {
+    const int per_block = QGK_LINK_ENVS * QGK_LINK_WAVES;
+    return dim3((s->n + per_block - 1) / per_block);
+}
+
+extern "C" int qg_step_device_seq(qg_sim *s, const float *actions, float *packed, int32_t count, void *stream) {
+    if (!s || !actions || !packed || count < 1) return fail(QG_ERR_ARG, "qg_step_device_seq: bad argument");
+    int rc = multi_step_usable(s, "qg_step_device_seq");
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    if (s->res.launched && (rc = resident_retire(s)) != QG_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (st != s->stream) {
+        s->caller_inflight = 1;
+        if (!s->captured_once) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) s->captured_once = 1;
+        }
+    }
+    KResident R = {};
+    R.actions = actions;
+    R.packed = packed;
+    R.count = count;
+    R.slots = 1;
+    const KStepArgs P = multi_step_args(s);
+    const dim3 g = multi_step_grid(s), b(QGK_WAVE * QGK_LINK_WAVES);
+    if (s->baked) hipLaunchKernelGGL((qg_step_kernel_link_multi<true, false>), g, b, 0, st, s->d_model, s->d_task, P, R);
+    else hipLaunchKernelGGL((qg_step_kernel_link_multi<false, false>), g, b, 0, st, s->d_model, s->d_task, P, R);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_step_kernel_link_multi launch: %s", hipGetErrorString(e));
+    return QG_OK;
+}
+
+static void resident_free(qg_sim *s) {
+    if (s->res.d_mail) (void)hipFree(s->res.d_mail);
+    if (s->res.own_buffers && s->res.k.actions) (void)hipFree((void *)s->res.k.actions);
+    if (s->res.own_buffers && s->res.k.packed) (void)hipFree(s->res.k.packed);
+    if (s->res.hstat) (void)hipHostFree((void *)s->res.hstat);
+    if (s->res.ctl_stream) (void)hipStreamDestroy(s->res.ctl_stream);
+    memset(&s->res, 0, sizeof s->res);
+}
+
+// The resident kernel stores the state it holds in registers and leaves: STOP into the door (the waves first finish what has been
+// rung), then the library's stream -- where the kernel runs -- is waited for.  Rings still queued on the caller's stream are waited
+// for first, so that "every step enqueued before this call" has run, as the ordering contract of quadgym.h says.
+static int resident_retire(qg_sim *s) {
+    if (!s->res.active || !s->res.launched) return QG_OK;
+    if (s->res.last_stream) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s->res.last_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+            return fail(QG_ERR_ARG, "the resident step kernel cannot be retired while its rings are being captured");
+        (void)hipStreamSynchronize(s->res.last_stream);      // (a stream the caller has destroyed since is no reason to fail)
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(qg_resident_ctl_kernel, dim3(1), dim3(64), 0, s->res.ctl_stream, s->res.k.door, 0);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(s->res.ctl_stream), QG_ERR_LAUNCH);
+    HIP_TRY(hipStreamSynchronize(s->stream), QG_ERR_LAUNCH);
+    s->res.launched = 0;
+    return QG_OK;
+}
+
+// (re)launch on the library's stream: clear STOP, then the kernel; it starts at the env-step the previous launch left off at
+static int resident_launch(qg_sim *s) {
+    s->res.hstat[0] = QG_RES_RUNNING;
+    hipLaunchKernelGGL(qg_resident_ctl_kernel, dim3(1), dim3(64), 0, s->stream, s->res.k.door, 1);
+    HIP_TRY(hipGetLastError(), QG_ERR_LAUNCH);
+    KStepArgs P = multi_step_args(s);
+    const dim3 g = multi_step_grid(s), b(QGK_WAVE * QGK_LINK_WAVES);
+    if (s->baked) hipLaunchKernelGGL((qg_step_kernel_link_multi<true, true>), g, b, 0, s->stream, s->d_model, s->d_task, P, s->res.k);
+    else hipLaunchKernelGGL((qg_step_kernel_link_multi<false, true>), g, b, 0, s->stream, s->d_model, s->d_task, P, s->res.k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "resident kernel launch: %s", hipGetErrorString(e));
+    s->res.launched = 1;
+    // (a ring on another stream that gets to the door before the two launches above sees STOP with `RUNNING` in hstat and waits for
+    // the door to open -- qg_resident_ring_kernel -- so nothing has to be waited for here)
+    return QG_OK;
+}
+
+extern "C" int qg_resident_start(qg_sim *s, int32_t slots, int32_t idle_timeout_us, float *actions, float *packed) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    if ((actions == nullptr) != (packed == nullptr)) return fail(QG_ERR_ARG, "qg_resident_start: pass both slot buffers or neither");
+    if (s->res.active) return fail(QG_ERR_ARG, "qg_resident_start: already on");
+    if (slots < 1 || slots > 4096) return fail(QG_ERR_ARG, "qg_resident_start: slots must be 1..4096");
+    if (idle_timeout_us == 0) idle_timeout_us = 2000;
+    if (idle_timeout_us < 50 || idle_timeout_us > 100000) return fail(QG_ERR_ARG, "qg_resident_start: idle_timeout_us must be 50..100000 (0 = 2000)");
+    int rc = multi_step_usable(s, "qg_resident_start");
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    const size_t n = (size_t)s->n, row = (size_t)s->obs_dim + 2;
+    const size_t mail_bytes = 256 + QG_RES_SHARDS * 128 + 256;
+    hipError_t e = hipMalloc(&s->res.d_mail, mail_bytes);
+    if (e == hipSuccess) e = hipMemset(s->res.d_mail, 0, mail_bytes);
+    s->res.own_buffers = actions == nullptr;
+    if (s->res.own_buffers) {
+        float *acts = nullptr;
+        if (e == hipSuccess) e = hipMalloc((void **)&acts, (size_t)slots * n * QG_NU * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(acts, 0, (size_t)slots * n * QG_NU * sizeof(float));
+        s->res.k.actions = acts;
+        if (e == hipSuccess) e = hipMalloc((void **)&s->res.k.packed, (size_t)slots * n * row * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(s->res.k.packed, 0, (size_t)slots * n * row * sizeof(float));
+    } else {
+        s->res.k.actions = actions;
+        s->res.k.packed = packed;
+    }
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->res.hstat, 64, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->res.ctl_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        resident_free(s);
+        return fail(QG_ERR_ALLOC, "qg_resident_start: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < 8; i++) s->res.hstat[i] = 0;
+    uint8_t *m = (uint8_t *)s->res.d_mail;
+    s->res.k.door = (unsigned long long *)m;
+    s->res.k.done = (unsigned long long *)(m + 256);
+    s->res.k.completed = (unsigned long long *)(m + 256 + QG_RES_SHARDS * 128);
+    s->res.k.hstat = (unsigned long long *)s->res.hstat;
+    s->res.k.slots = slots;
+    s->res.k.count = 0;
+    s->res.k.idle_ticks = (uint32_t)idle_timeout_us * 100u;
+    s->res.k.ring_ticks = 20000000u;          // 200 ms without a single arrival: the ring gives up and says so
+    s->res.active = 1;
+    s->res.rung = 0;
+    return resident_launch(s);
+}
+
+extern "C" int qg_resident_stop(qg_sim *s) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    if (!s->res.active) return QG_OK;
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    int rc = resident_retire(s);
+    if (rc != QG_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
+    resident_free(s);
+    return QG_OK;
+}
+
+extern "C" int qg_resident_buffers(qg_sim *s, float **actions, float **packed, int32_t *slots) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    if (!s->res.active) return fail(QG_ERR_ARG, "qg_resident_buffers: the resident step mode is off");
+    if (actions) *actions = (float *)s->res.k.actions;
+    if (packed) *packed = s->res.k.packed;
+    if (slots) *slots = s->res.k.slots;
+    return QG_OK;
+}
+
+// rings that found the kernel retired, or gave up waiting, since the last look: an error the caller must see once
+static int resident_check_reports(qg_sim *s, const char *who) {
+    const uint64_t lost = s->res.hstat[2], gave = s->res.hstat[3];
+    if (lost != s->res.lost_seen) {
+        const uint64_t d = lost - s->res.lost_seen;
+        s->res.lost_seen = lost;
+        return fail(QG_ERR_LAUNCH, "%s: %llu env-step(s) were rung after the resident kernel had retired and were NOT executed "
+                    "(rings must follow one another within the idle time-out, or call qg_resident_ensure before a burst)", who, (unsigned long long)d);
+    }
+    if (gave != s->res.gaveup_seen) {
+        s->res.gaveup_seen = gave;
+        return fail(QG_ERR_LAUNCH, "%s: a ring gave up waiting for the resident kernel (no arrival for 200 ms)", who);
+    }
+    return QG_OK;
+}
+
+extern "C" int qg_resident_ensure(qg_sim *s) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    if (!s->res.active) return fail(QG_ERR_ARG, "qg_resident_ensure: the resident step mode is off");
+    HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    if (s->res.launched && s->res.hstat[0] == QG_RES_RUNNING) return QG_OK;
+    return resident_launch(s);        // stream-ordered behind the launch that has left (or is leaving)
+}
+
+extern "C" int qg_resident_step_device(qg_sim *s, int32_t count, void *stream) {
+    if (!s || count < 1) return fail(QG_ERR_ARG, "qg_resident_step_device: bad argument");
+    if (!s->res.active) return fail(QG_ERR_ARG, "qg_resident_step_device: the resident step mode is off (qg_resident_start)");
+    if (count > s->res.k.slots) return fail(QG_ERR_ARG, "qg_resident_step_device: count %d exceeds the %d slots of the mailbox", count, s->res.k.slots);
+    if ((hipStream_t)stream == s->stream) return fail(QG_ERR_ARG, "qg_resident_step_device: that is the stream the resident kernel occupies");
+    int rc = resident_check_reports(s, "qg_resident_step_device");
+    if (rc != QG_OK) return rc;
+    if ((rc = qg_resident_ensure(s)) != QG_OK) return rc;
+    const unsigned nwaves = multi_step_grid(s).x * QGK_LINK_WAVES;
+    hipLaunchKernelGGL(qg_resident_ring_kernel, dim3(1), dim3(QGK_WAVE), 0, (hipStream_t)stream, s->res.k, (unsigned)count, nwaves);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "ring kernel launch: %s", hipGetErrorString(e));
+    s->res.last_stream = (hipStream_t)stream;
+    s->res.rung += count;
+    return QG_OK;
+}
+
+extern "C" int qg_resident_status(qg_sim *s, int64_t *rung, int32_t *running, int64_t *completed_at_exit, int64_t *not_executed) {
+    if (!s) return fail(QG_ERR_ARG, "null handle");
+    if (!s->res.active) return fail(QG_ERR_ARG, "qg_resident_status: the resident step mode is off");
+    if (rung) *rung = s->res.rung;
+    if (running) *running = s->res.launched && s->res.hstat[0] == QG_RES_RUNNING;
+    if (completed_at_exit) *completed_at_exit = (int64_t)s->res.hstat[1];
+    if (not_executed) *not_executed = (int64_t)s->res.hstat[2];
     return QG_OK;
 }
 
@@ -809,6 +1058,7 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     // one task layer per simulator: a second one would save the flags the first has already switched (flip termination, data.ctrl
     // tracking) as "what the sim had", and whichever is destroyed first would switch them off under the other
     if (s->walk_bound) return fail(QG_ERR_ARG, "qg_walk_create: a walking task layer is already bound to this simulator (destroy it first)");
+    if (s->res.active) return fail(QG_ERR_ARG, "qg_walk_create: the resident step mode is on (qg_resident_stop first)");
     qg_walk_params dp;
     if (!params) { qg_walk_default_params(&dp); params = &dp; }
     if (!(params->min_freq > 0) || !(params->ema_alpha >= 0 && params->ema_alpha <= 1)) return fail(QG_ERR_ARG, "qg_walk_create: bad estimator parameters");
@@ -1142,6 +1392,7 @@ extern "C" int qg_walk_set_state(qg_walk *w, const void *blob) {
 extern "C" int qg_get_reset_streams(qg_sim *s, int32_t *episode, uint64_t *seed) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     if (episode) HIP_TRY(hipMemcpy(episode, s->st.episode, (size_t)s->n * sizeof(int32_t), hipMemcpyDeviceToHost), QG_ERR_DEVICE);
     if (seed) *seed = s->seed;
@@ -1150,6 +1401,7 @@ extern "C" int qg_get_reset_streams(qg_sim *s, int32_t *episode, uint64_t *seed)
 extern "C" int qg_set_reset_streams(qg_sim *s, const int32_t *episode, uint64_t seed) {
     if (!s) return fail(QG_ERR_ARG, "null handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    { int rr = resident_retire(s); if (rr != QG_OK) return rr; }
     HIP_TRY(hipDeviceSynchronize(), QG_ERR_LAUNCH);
     if (episode) HIP_TRY(hipMemcpy(s->st.episode, episode, (size_t)s->n * sizeof(int32_t), hipMemcpyHostToDevice), QG_ERR_DEVICE);
     s->seed = seed;

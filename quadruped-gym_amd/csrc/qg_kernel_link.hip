@@ -102,6 +102,19 @@ DEV float leg_prefix(float x) {
 }
 DEV V3 leg_prefix(V3 a) { return v3(leg_prefix(a.x), leg_prefix(a.y), leg_prefix(a.z)); }
 
+// The quaternion scaled to unit length at the head of an env-step.  The sum of squares is written out as explicit multiply-adds: left
+// to the compiler's contraction, w*w + x*x may become fma(w, w, x*x) in one kernel and fma(x, x, w*w) in another (it did: the
+// per-launch kernel and the many-steps-per-launch kernel of qg_kernel_resident.hip differed by one ulp in a few envs per step),
+// and those two kernels must leave the same bits.
+DEV void quat_unit(BaseState &B) {
+    float d = B.qx * B.qx;
+    d = fmaf(B.qw, B.qw, d);
+    d = fmaf(B.qy, B.qy, d);
+    d = fmaf(B.qz, B.qz, d);
+    const float qn = __builtin_amdgcn_rsqf(d);
+    B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
+}
+
 // what link r needs as per-lane data (registers)
 struct LinkRegs {
     float mass, ipos[3], inertia[6], cp[QGK_CP_LINK][3];
@@ -506,46 +519,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
         }
     }
 
-    // per-lane constants of link r: selected among the three links' LITERALS (two v_cndmask each, ~90 instructions once per launch)
-    // rather than loaded from a table -- a load round trip behind the state loads cost ~1 us of a 16 us launch in round 1; round 3
-    // tried again with ten wide loads of the model constant issued AHEAD of the state loads: 78 instructions fewer, 0.07 us slower
-    // (11.89 against 11.82 us per step, same box).  The spare lane
-    // carries no mass and no inertia; its contact is switched off in the substep.
-    LinkRegs K;
-    {
-        const int rk = r < 2 ? r : 2;
-        const KLink &L0 = C.link[0], &L1 = C.link[1], &L2 = C.link[2];
-        const KLink &Lown = C.link[3 * k + rk];     // !BAKED: this lane's own link, read from the staged table
-        const float ml = r < 3 ? 1.f : 0.f;
-        // picked with multiply-adds on 0 / 1 lane masks (exact: x * 1 + 0): three instructions per value with the literals folded into
-        // v_mul / v_fmamk, against mov + cndmask + mov + cndmask (a VOP3 select takes no literal)
-        const float s0 = rk == 0 ? 1.f : 0.f, s1 = rk == 1 ? 1.f : 0.f, s2 = rk == 2 ? 1.f : 0.f;
-        // a value the three links share (the compiled-in robot's servo and hinge parameters) stays a literal: no register, and the
-        // substep's products of such values fold at compile time (the comparison is on constants of QG_BAKED_MODEL)
-#define QG_SEL(field) (BAKED ? ((L0.field == L1.field && L1.field == L2.field) ? L0.field \
-                                                                               : fmaf(s2, L2.field, fmaf(s1, L1.field, s0 * L0.field))) \
-                             : Lown.field)
-        K.mass = ml * QG_SEL(mass);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) K.ipos[i] = QG_SEL(ipos[i]);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) K.inertia[i] = ml * QG_SEL(inertia[i]);
-#pragma unroll
-        for (int i = 0; i < QGK_CP_LINK; ++i) { K.cp[i][0] = QG_SEL(cp[i][0]); K.cp[i][1] = QG_SEL(cp[i][1]); K.cp[i][2] = QG_SEL(cp[i][2]); }
-        K.lo = QG_SEL(lo); K.hi = QG_SEL(hi); K.damping = QG_SEL(damping); K.armature = QG_SEL(armature); K.kp = QG_SEL(kp);
-        K.kv = QG_SEL(kv); K.gear = QG_SEL(gear); K.force_lo = QG_SEL(force_lo); K.force_hi = QG_SEL(force_hi);
-        K.act_decay = QG_SEL(act_decay);
-        K.ml = ml;
-        // the lane's sample point of the FRAME: the compiled-in robot's twelve are three points and their quarter-turn copies (index
-        // 4 o + k = point o turned by leg k's quarter turn); any other robot: any partition of the twelve over the twelve link lanes
-        if constexpr (BAKED) {
-            const float fx = sel3(rk, C.cp0[0][0], C.cp0[4][0], C.cp0[8][0]), fy = sel3(rk, C.cp0[0][1], C.cp0[4][1], C.cp0[8][1]);
-            K.cpF[0] = cm * fx - sm * fy; K.cpF[1] = sm * fx + cm * fy; K.cpF[2] = sel3(rk, C.cp0[0][2], C.cp0[4][2], C.cp0[8][2]);
-        } else {
-            K.cpF[0] = C.cp0[3 * k + rk][0]; K.cpF[1] = C.cp0[3 * k + rk][1]; K.cpF[2] = C.cp0[3 * k + rk][2];
-        }
-#undef QG_SEL
-    }
+#include "qg_link_regs.inc"
 
     BaseState B;
     const unsigned n4 = 4u * (unsigned)n, e4 = 4u * (unsigned)env;        // byte strides of the [field][n] state arrays
@@ -553,10 +527,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     B.qw = lk_ld(P.st.qpos, 3 * n4 + e4); B.qx = lk_ld(P.st.qpos, 4 * n4 + e4); B.qy = lk_ld(P.st.qpos, 5 * n4 + e4); B.qz = lk_ld(P.st.qpos, 6 * n4 + e4);
     B.vw = v3(lk_ld(P.st.qvel, e4), lk_ld(P.st.qvel, n4 + e4), lk_ld(P.st.qvel, 2 * n4 + e4));
     B.wb = v3(lk_ld(P.st.qvel, 3 * n4 + e4), lk_ld(P.st.qvel, 4 * n4 + e4), lk_ld(P.st.qvel, 5 * n4 + e4));
-    {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised
-        const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
-        B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
-    }
+    quat_unit(B);   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised
     const int nstep0 = lk_ld(P.st.nstep, e4);
     // this lane's hinge (the spare lane shadows hinge 2 of its leg: same loads, nothing of it is ever stored)
     const int rk = r < 3 ? r : 2;

@@ -140,6 +140,56 @@ class BatchedSim:
                 check(-1, "qg_step_device_packed")
         return step
 
+    # -- many env-steps per launch (include/quadgym.h: qg_step_device_seq, qg_resident_*) ---------------------------------------
+    def step_device_seq(self, actions, packed, stream=None):
+        """ONE launch runs ``K`` env-steps: ``actions[K, n, 12] -> packed[K, n, obs_dim + 2]`` with the state in registers in
+        between (open-loop sequences).  Bit-identical to ``K`` calls of ``step_device_packed``."""
+        import torch
+        k = int(actions.shape[0])
+        self._check_tensor(actions, (k, self.n, NU), torch.float32)
+        self._check_tensor(packed, (k, self.n, self.obs_dim + 2), torch.float32)
+        check(self._lib.qg_step_device_seq(self._h, actions.data_ptr(), packed.data_ptr(), k, self._stream_ptr(stream)),
+              "qg_step_device_seq")
+
+    def resident_start(self, actions, packed, idle_timeout_us: int = 0):
+        """Launch the RESIDENT step kernel on the mailbox ``actions[slots, n, 12]`` / ``packed[slots, n, obs_dim + 2]`` (torch tensors
+        the caller keeps alive until ``resident_stop``).  Env-step ``i`` of the resident sequence uses slot ``i % slots``."""
+        import torch
+        slots = int(actions.shape[0])
+        self._check_tensor(actions, (slots, self.n, NU), torch.float32)
+        self._check_tensor(packed, (slots, self.n, self.obs_dim + 2), torch.float32)
+        torch.cuda.synchronize(self.device)        # whatever filled the slots has landed before the kernel may read them
+        check(self._lib.qg_resident_start(self._h, slots, int(idle_timeout_us), actions.data_ptr(), packed.data_ptr()),
+              "qg_resident_start")
+        self._resident_keep = (actions, packed)
+
+    def resident_step(self, count: int = 1, stream=None):
+        """Ring ``count`` env-steps on ``stream`` (default: torch's current stream): what follows on that stream finds their rows
+        in the output slots."""
+        check(self._lib.qg_resident_step_device(self._h, int(count), self._stream_ptr(stream)), "qg_resident_step_device")
+
+    def bind_resident_step(self, count: int = 1, stream=None):
+        st = self._stream_ptr(stream)
+        fn, h, c = self._lib.qg_resident_step_device, self._h, int(count)
+
+        def ring():
+            if fn(h, c, st) != 0:
+                check(-1, "qg_resident_step_device")
+        return ring
+
+    def resident_ensure(self):
+        check(self._lib.qg_resident_ensure(self._h), "qg_resident_ensure")
+
+    def resident_status(self):
+        """``dict(rung, running, completed_at_exit, not_executed)`` -- no synchronisation."""
+        rung, run, comp, lost = C.c_int64(0), C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        check(self._lib.qg_resident_status(self._h, C.byref(rung), C.byref(run), C.byref(comp), C.byref(lost)), "qg_resident_status")
+        return {"rung": int(rung.value), "running": bool(run.value), "completed_at_exit": int(comp.value), "not_executed": int(lost.value)}
+
+    def resident_stop(self):
+        check(self._lib.qg_resident_stop(self._h), "qg_resident_stop")
+        self._resident_keep = None
+
     def time_step_kernel(self, actions, packed, iters: int) -> float:
         """Mean milliseconds per launch of the step kernel over ``iters`` back-to-back launches,
         measured with HIP events on the stream the kernel is launched on."""

@@ -1,0 +1,308 @@
+"""Many env-steps per launch (include/quadgym.h: qg_step_device_seq and the RESIDENT form qg_resident_*): both must leave exactly the
+bits of the per-launch one-link-per-lane kernel -- they run the same substep code on state that stays in registers between env-steps
+(/root/reference keeps it in MjData across steps the same way, src/envs/quadruped.py:163-165) -- and the resident kernel must never
+be able to hang: it leaves by itself when nobody rings, and every entry point that needs the state in memory retires it first."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from quadruped_gym_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "step_vectors.npz")
+
+
+def _task(frame_skip=4, imu=False, max_time=0.2, yaw=True):
+    t = _abi.default_task()
+    t.frame_skip = frame_skip
+    t.auto_reset = 1
+    t.max_time = max_time                             # short episodes: several auto-resets inside every test
+    t.use_fall = 1
+    t.fall_height = 0.05
+    t.reset_flags = _abi.RESET_RANDOM_YAW if yaw else 0
+    if imu:
+        t.obs_mode = 1
+    return t
+
+
+def _twin(n, task, seed=5):
+    from quadruped_gym_amd.sim import BatchedSim
+    a, b = BatchedSim(n, task=task), BatchedSim(n, task=task)
+    assert a.mapping == _abi.MAP_LINK
+    a.reset(seed=seed, flags=task.reset_flags); b.reset(seed=seed, flags=task.reset_flags)
+    return a, b
+
+
+def _sync():
+    # the caller's stream only: a device-wide wait (torch.cuda.synchronize) also waits for the resident kernel, i.e. until it has
+    # left for lack of rings
+    import torch
+    torch.cuda.current_stream().synchronize()
+
+
+def _same_state(a, b):
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert np.array_equal(x, y)
+    ea, eb = a.get_reset_streams(), b.get_reset_streams()
+    assert np.array_equal(ea[0], eb[0]) and ea[1] == eb[1]
+    return ea[0]
+
+
+@pytest.mark.parametrize("n,fs,imu", [(4096, 4, False), (1000, 4, False), (3, 20, True), (4096, 20, True)])
+def test_sequence_launch_is_bit_identical_to_per_step_launches(n, fs, imu):
+    """ONE launch of K env-steps against K launches of the per-launch kernel: same packed rows, same final state, same episode
+    counters -- through auto-resets with random yaw (25 or 5 env-steps per episode), a ragged last workgroup, both observation packs."""
+    import torch
+    K, rounds = 24, 4
+    task = _task(fs, imu)
+    a, b = _twin(n, task)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    finished = 0
+    for rnd in range(rounds):
+        acts = torch.rand((K, n, 12), generator=gen, device=dev) * 3 - 1.5          # beyond the clip range on purpose
+        pa = torch.empty((K, n, a.obs_dim + 2), device=dev)
+        pb = torch.empty((K, n, a.obs_dim + 2), device=dev)
+        a.step_device_seq(acts, pa)
+        for k in range(K):
+            b.step_device_packed(acts[k], pb[k])
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb), rnd
+        finished += int(pa[:, :, -1].sum())
+    assert finished >= 2 * n
+    ep = _same_state(a, b)
+    assert ep.min() >= 2
+    a.close(); b.close()
+
+
+def test_sequence_launch_matches_golden_vectors():
+    """The golden states (tests/golden/step_vectors.npz: rollout states plus FRAME / femur contacts) through a sequence launch of ONE
+    env-step: the same bits as the per-launch kernel, which tests/test_parity_gpu.py checks against the fixture and the oracle."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    gold = dict(np.load(GOLD))
+    n = len(gold["qpos"])
+    task = _abi.default_task()
+    task.use_fall = 1
+    task.fall_height = 0.05
+    a, b = BatchedSim(n, task=task), BatchedSim(n, task=task)
+    for s in (a, b):
+        s.set_mapping(_abi.MAP_LINK)
+        s.set_state(gold["qpos"], gold["qvel"], gold["act"], None, gold["nstep"])
+    dev = torch.device("cuda:0")
+    acts = torch.from_numpy(gold["actions"].astype(np.float32)).to(dev)
+    pa = torch.empty((1, n, 35), device=dev); pb = torch.empty((n, 35), device=dev)
+    a.step_device_seq(acts[None].contiguous(), pa)
+    b.step_device_packed(acts, pb)
+    torch.cuda.synchronize()
+    assert torch.equal(pa[0], pb)
+    _same_state(a, b)
+    # and against the fixture itself, within the stated one-step tolerances of tests/test_parity_gpu.py
+    q1 = a.get_state()[0]
+    assert np.abs(q1 - gold["A_qpos1"]).max() <= 5e-6 + 2e-6 * np.abs(gold["A_qpos1"]).max()
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,slots", [(4096, 1), (4096, 4), (1000, 2)])
+def test_resident_closed_loop_is_bit_identical_to_per_step_launches(n, slots):
+    """The resident kernel rung ONE env-step at a time (a policy in the loop: fresh actions written into the slot before every ring,
+    the rows read back after it) against the per-launch kernel: every step's rows, the final state, the episode counters -- 120
+    env-steps through auto-resets with random yaw."""
+    import torch
+    steps = 120
+    task = _task()
+    a, b = _twin(n, task)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(2)
+    mail_a = torch.zeros((slots, n, 12), device=dev)
+    mail_p = torch.zeros((slots, n, 35), device=dev)
+    pb = torch.empty((n, 35), device=dev)
+    a.resident_start(mail_a, mail_p)
+    finished = 0
+    for i in range(steps):
+        act = torch.rand((n, 12), generator=gen, device=dev) * 3 - 1.5
+        s = i % slots
+        mail_a[s].copy_(act)                          # the "policy": a kernel on the caller's stream writes the slot ...
+        a.resident_step(1)                            # ... the ring makes the step runnable and holds the stream until its rows are out
+        got = mail_p[s].clone()
+        b.step_device_packed(act, pb)
+        _sync()
+        assert torch.equal(got, pb), i
+        finished += int(pb[:, 34].sum())
+    assert finished >= 3 * n
+    st = a.resident_status()
+    assert st["rung"] == steps and st["not_executed"] == 0
+    _same_state(a, b)                                 # get_state retires the kernel: the registers' state is in memory
+    a.resident_stop(); a.close(); b.close()
+
+
+def test_resident_run_ahead_rings_many_steps_at_once():
+    """Rings of 16 env-steps over a 16-slot mailbox (the kernel runs ahead through slots filled beforehand), then per-launch steps
+    on the same handle (which retire the kernel), then rings again: one continuous trajectory, bit-identical to a per-launch twin."""
+    import torch
+    n, slots = 4096, 16
+    task = _task()
+    a, b = _twin(n, task)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    mail_a = torch.zeros((slots, n, 12), device=dev)
+    mail_p = torch.zeros((slots, n, 35), device=dev)
+    pb = torch.empty((slots, n, 35), device=dev)
+    one = torch.empty((n, 35), device=dev)
+    a.resident_start(mail_a, mail_p)
+    for rnd in range(6):
+        mail_a.copy_(torch.rand((slots, n, 12), generator=gen, device=dev) * 2 - 1)
+        a.resident_step(slots)
+        for k in range(slots):
+            b.step_device_packed(mail_a[k], pb[k])
+        _sync()
+        assert torch.equal(mail_p, pb), rnd
+        if rnd == 2:                                  # a per-launch step in between: the resident kernel hands the state back first
+            act = torch.rand((n, 12), generator=gen, device=dev)
+            a.step_device_packed(act, one)
+            b.step_device_packed(act, pb[0])
+            _sync()
+            assert torch.equal(one, pb[0])
+            assert not a.resident_status()["running"]
+            # the mailbox goes on where the resident sequence stood (96 env-steps rung so far: slot 0 again)
+    _same_state(a, b)
+    a.resident_stop(); a.close(); b.close()
+
+
+def test_resident_kernel_leaves_by_itself_and_the_handle_stays_usable():
+    """Nobody rings: within the idle time-out (here 1 ms) the kernel has stored its state and left -- seen from the host without any
+    synchronisation -- and the handle is usable at once: state read-back, a ring (which launches it again), a reset."""
+    import torch
+    n = 4096
+    task = _task()
+    a, b = _twin(n, task)
+    dev = torch.device("cuda:0")
+    mail_a = torch.rand((1, n, 12), device=dev)
+    mail_p = torch.zeros((1, n, 35), device=dev)
+    pb = torch.empty((n, 35), device=dev)
+    a.resident_start(mail_a, mail_p, idle_timeout_us=1000)
+    assert a.resident_status()["running"]
+    t0 = time.perf_counter()
+    while a.resident_status()["running"] and time.perf_counter() - t0 < 1.0:
+        time.sleep(0.0005)
+    gone_after = time.perf_counter() - t0
+    assert not a.resident_status()["running"] and gone_after < 0.010, gone_after          # within 10 ms, no doorbell ever rung
+    t0 = time.perf_counter()
+    _same_state(a, b)                                 # usable at once (nothing to wait for: the kernel is gone)
+    assert time.perf_counter() - t0 < 0.010
+    a.resident_step(1)                                # launches the kernel again, then rings
+    b.step_device_packed(mail_a[0], pb)
+    _sync()
+    assert torch.equal(mail_p[0], pb)
+    assert a.resident_status()["not_executed"] == 0
+    a.reset(seed=9, flags=task.reset_flags); b.reset(seed=9, flags=task.reset_flags)       # retires it again
+    a.resident_step(1)
+    b.step_device_packed(mail_a[0], pb)
+    _sync()
+    assert torch.equal(mail_p[0], pb)
+    _same_state(a, b)
+    a.resident_stop(); a.close(); b.close()
+
+
+def test_ring_that_meets_a_retired_kernel_runs_nothing_and_says_so():
+    """A ring replayed from a hipGraph after the kernel has left (the host check of qg_resident_step_device is not part of a replay):
+    the env-steps are NOT executed, the state stays that of the last executed step, and the next resident call reports it."""
+    import torch
+    n = 512
+    task = _task()
+    a, b = _twin(n, task)
+    dev = torch.device("cuda:0")
+    mail_a = torch.rand((1, n, 12), device=dev)
+    mail_p = torch.zeros((1, n, 35), device=dev)
+    a.resident_start(mail_a, mail_p, idle_timeout_us=500)
+    side = torch.cuda.Stream(dev)
+    _sync()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        a.resident_step(1, stream=torch.cuda.current_stream(dev))
+    graph.replay(); _sync()          # (capture does not execute: this is env-step 0)
+    pb = torch.empty((n, 35), device=dev)
+    b.step_device_packed(mail_a[0], pb)
+    _sync()
+    assert torch.equal(mail_p[0], pb)
+    time.sleep(0.02)                                  # the kernel leaves (0.5 ms idle) ...
+    assert not a.resident_status()["running"]
+    before = mail_p.clone()
+    graph.replay(); _sync()          # ... and the replayed ring meets a retired door
+    assert a.resident_status()["not_executed"] == 1
+    assert torch.equal(mail_p, before)
+    with pytest.raises(_abi.QuadGymError, match="NOT executed"):
+        a.resident_step(1)
+    _same_state(a, b)                                 # one env-step has run, not two
+    a.resident_ensure()                               # what a caller does before replaying captured rings
+    graph.replay(); _sync()
+    b.step_device_packed(mail_a[0], pb); _sync()
+    assert torch.equal(mail_p[0], pb)
+    _same_state(a, b)
+    a.resident_stop(); a.close(); b.close()
+
+
+def test_resident_rings_replay_from_a_hipgraph():
+    """A graph of 8 rings (one env-step each, the slot's actions rewritten by a captured copy in front of every ring) replayed 15
+    times -- 120 env-steps without a host call per step -- against eager per-launch steps of a twin."""
+    import torch
+    n, G, R = 4096, 8, 15
+    task = _task()
+    a, b = _twin(n, task)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(4)
+    acts = torch.rand((G, n, 12), generator=gen, device=dev) * 2 - 1
+    mail_a = torch.zeros((1, n, 12), device=dev)
+    mail_p = torch.zeros((1, n, 35), device=dev)
+    rows = torch.zeros((G, n, 35), device=dev)
+    pb = torch.empty((G, n, 35), device=dev)
+    a.resident_start(mail_a, mail_p, idle_timeout_us=20000)
+    side = torch.cuda.Stream(dev)
+    _sync()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        for g in range(G):
+            mail_a[0].copy_(acts[g])
+            a.resident_step(1, stream=torch.cuda.current_stream(dev))
+            rows[g].copy_(mail_p[0])
+    for rep in range(R):
+        a.resident_ensure()
+        graph.replay()
+        for g in range(G):
+            b.step_device_packed(acts[g], pb[g])
+        _sync()
+        assert torch.equal(rows, pb), rep
+    assert a.resident_status()["not_executed"] == 0
+    ep = _same_state(a, b)
+    assert ep.min() >= 4
+    a.resident_stop(); a.close(); b.close()
+
+
+def test_resident_and_sequence_forms_refuse_what_they_do_not_cover():
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    dev = torch.device("cuda:0")
+    big = BatchedSim(8192)                            # AUTO = one leg per lane
+    with pytest.raises(_abi.QuadGymError, match="one-link-per-lane"):
+        big.step_device_seq(torch.zeros((2, 8192, 12), device=dev), torch.zeros((2, 8192, 35), device=dev))
+    big.close()
+    t = _abi.default_task()
+    t.auto_reset = 1
+    t.reset_flags = _abi.RESET_JOINT_JITTER
+    jit = BatchedSim(64, task=t)
+    with pytest.raises(_abi.QuadGymError, match="jitter"):
+        jit.resident_start(torch.zeros((1, 64, 12), device=dev), torch.zeros((1, 64, 35), device=dev))
+    jit.close()
+    sim = BatchedSim(64)
+    ma, mp = torch.zeros((2, 64, 12), device=dev), torch.zeros((2, 64, 35), device=dev)
+    sim.resident_start(ma, mp)
+    with pytest.raises(_abi.QuadGymError, match="slots"):
+        sim.resident_step(3)
+    with pytest.raises(_abi.QuadGymError, match="resident"):
+        sim.set_mapping(_abi.MAP_QUAD)
+    sim.resident_stop()
+    sim.set_mapping(_abi.MAP_QUAD)
+    sim.close()
