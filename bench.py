@@ -169,6 +169,13 @@ def main():
     ap.add_argument("--no-track-ctrl", action="store_true",
                     help="development only: skip the data.ctrl write-back (48 B/env) the reference's step maintains; such a line is "
                          "marked `ctrl_tracking: false` and is not the reported configuration")
+    ap.add_argument("--seq", type=int, default=0, metavar="S",
+                    help="opt-in: ONE launch per S env-steps (qg_step_device_seq: the state stays in registers between the env-steps of "
+                         "a launch; open-loop action sequences).  One GPU, plain step, one-link-per-lane mapping")
+    ap.add_argument("--resident", choices=["closed", "ahead"], default=None,
+                    help="opt-in: the RESIDENT step kernel (qg_resident_*): launched once, handed every env-step through a mailbox of 16 "
+                         "action / output slots.  closed: one ring per env-step on the timed stream (a policy in the loop would sit "
+                         "between two rings); ahead: one ring per 16 env-steps (the kernel runs ahead through the slots).  One GPU")
     args = ap.parse_args()
 
     import torch
@@ -267,6 +274,33 @@ def main():
 
     step_fn = sim.bind_step_packed(pool, packed, stream=compute)
 
+    # ---- opt-in forms that keep the state in registers across env-steps (include/quadgym.h: qg_step_device_seq, qg_resident_*) ----
+    multi = None
+    if args.seq or args.resident:
+        if world > 1 or use_dist or walk is not None or args.graph > 0 or (args.seq and args.resident):
+            raise SystemExit("--seq / --resident: one GPU, plain step, no --graph, one of the two")
+        chunk = args.seq if args.seq else (16 if args.resident == "ahead" else 1)
+        slots = max(16, chunk)
+        # the action pool IS the mailbox: [slots, n, 12], env-step i reads slot i % slots -- a fresh action buffer every step
+        pool_t = torch.stack([pool[i % 16] for i in range(slots)]).contiguous()
+        rows_t = torch.empty((slots, n, row), device=dev)
+        args.steps = -(-args.steps // slots) * slots
+        args.warmup = -(-max(args.warmup, slots) // slots) * slots
+        if args.resident:
+            sim.resident_start(pool_t, rows_t)
+            ring = sim.bind_resident_step(chunk, stream=compute)
+        multi = {"chunk": chunk, "slots": slots}
+
+    def run_multi(k0, count):
+        if args.resident:
+            for _ in range(count // multi["chunk"]):
+                ring()
+            return
+        S = multi["chunk"]
+        for k in range(k0, k0 + count, S):
+            o = k % multi["slots"]
+            sim.step_device_seq(pool_t[o:o + S], rows_t[o:o + S], stream=compute)
+
     def run_eager(k0, count):
         for k in range(k0, k0 + count):
             b = k & 1
@@ -329,6 +363,8 @@ def main():
         build_graph(G)
 
     def run(k0, count):
+        if multi is not None:
+            return run_multi(k0, count)
         if native is not None:
             check(lib.qg_comm_rollout(native, a_arr, len(pool), p_arr, g_arr, count, 0), "qg_comm_rollout")
             return
@@ -342,7 +378,12 @@ def main():
             check(lib.qg_comm_synchronize(native), "qg_comm_synchronize")
         if gatherer is not None:
             gatherer.drain()
-        torch.cuda.synchronize(dev)
+        if args.resident:
+            # the timed stream: a ring completes when its env-steps' rows are in memory, so this IS the fence of the measured work; a
+            # device-wide wait would also wait for the resident kernel itself, i.e. until it leaves for lack of rings (2 ms)
+            compute.synchronize()
+        else:
+            torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -450,6 +491,11 @@ def main():
         total_envs = n * world
         value = total_envs * args.steps / dt
         bytes_step = algorithmic_bytes_per_env_step(od)
+        if multi is not None:
+            # what these forms move per env-step: the action in, the packed row out; the state (and data.ctrl) once per LAUNCH
+            traffic, valu, flops, stale, prof_id = None, None, None, None, None
+            per_launch = 196 + 4 + 196 + 4 + 48
+            bytes_step = 48 + 4 * od + 4 + 4 + (per_launch / multi["chunk"] if args.seq else 0)
         ach = bytes_step * n / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
@@ -461,6 +507,11 @@ def main():
                                    + (", random yaw at reset" if args.random_yaw else "")
                                    + (f", hinge jitter {args.joint_jitter} rad at reset" if args.joint_jitter > 0 else "")
                                    + (f", hipGraph of {args.graph} env-steps per replay" if args.graph > 0 else "")
+                                   + (", cycled through a pool of 16 pre-generated action buffers")
+                                   + (f"; OPT-IN sequence form: one launch per {args.seq} env-steps, state in registers in between" if args.seq else "")
+                                   + ("; OPT-IN resident form: one launch for the run, every env-step handed over through a mailbox of "
+                                      f"{multi['slots']} action / output slots, " + ("ONE ring kernel per env-step on the timed stream (closed loop)"
+                                      if args.resident == "closed" else "one ring per 16 env-steps (run-ahead)") if args.resident else "")
                                    + (", WALKING task layer (estimator + 11-term reward + flip termination), one launch per env-step" if args.walking else "")
                                    + (f", per-step RCCL gather of [{n},{row}] f32 to rank 0 from the library's C loop (qg_comm_rollout, overlapped)" if native is not None else
                                       (f", per-step RCCL {args.gather_op} of [{n},{row}] f32 to rank 0 ({'sync' if args.sync_gather else 'overlapped'})" if use_dist else "")),
@@ -470,7 +521,8 @@ def main():
             "state_finite": healthy,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "profile_stale": stale, "profile_build_id": prof_id, "build_id": build_id,
-                         "kernel": MAP_KERNEL[sim.mapping],
+                         "kernel": MAP_KERNEL[sim.mapping] if multi is None else "qg_step_kernel_link_multi",
+                         "fence": "timed-stream synchronize (rings complete when their rows are out)" if args.resident else "device synchronize",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_step * n,
                          "algorithmic_bytes_per_env_step": bytes_step,
                          "note": "VALU-issue-bound path (no dense contraction): ~0.6 KB of state traffic per env-step against "

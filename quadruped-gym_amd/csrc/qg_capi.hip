@@ -876,7 +876,8 @@ extern "C" int qg_resident_step_device(qg_sim *s, int32_t count, void *stream) {
     if (rc != QG_OK) return rc;
     if ((rc = qg_resident_ensure(s)) != QG_OK) return rc;
     const unsigned nwaves = multi_step_grid(s).x * QGK_LINK_WAVES;
-    hipLaunchKernelGGL(qg_resident_ring_kernel, dim3(1), dim3(QGK_WAVE), 0, (hipStream_t)stream, s->res.k, (unsigned)count, nwaves);
+    hipLaunchKernelGGL(qg_resident_ring_kernel, dim3(1), dim3(QGK_WAVE), 0, (hipStream_t)stream, s->res.k, (unsigned)count, nwaves,
+                       (unsigned long long)s->res.rung);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "ring kernel launch: %s", hipGetErrorString(e));
     s->res.last_stream = (hipStream_t)stream;

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's rows have left (write-through stores)
                 if (lane == 0) (void)__hip_atomic_fetch_add(my_done, (unsigned long long)unreported, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unreported = 0;
+                QG_MARK(5);                                                   // rows drained, arrival issued
             }
             if (seen <= kdone) {                                              // ... then wait for the next ring
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
                     const unsigned long long v = res_load_u64(R.door);
                     if ((v & ~QG_DOOR_STOP) > kdone) { seen = v & ~QG_DOOR_STOP; go = true; exit_code = QG_RES_EXIT_STOP; break; }
                     if (v & QG_DOOR_STOP) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)R.idle_ticks) {
+                    if ((polls & 3) == 3 && __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)R.idle_ticks) {
                         // nobody rang: retire the kernel -- unless a ring gets in first (then the swap fails and the next poll sees it)
                         if (lane == 0) {
                             unsigned long long expect = kdone;
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
                     if (polls < 256) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(32);
                 }
                 if (!go) break;
+                QG_MARK(1);                                                   // the ring seen
             }
         } else {
             if (kdone >= (unsigned long long)R.count) break;
@@ -169,6 +171,10 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             if constexpr (DOOR) a_next = res_load_action(R.actions, (size_t)(slot + 1 >= R.slots ? 0 : slot + 1) * slot_act + a_off);
             else a_next = lk_ld(R.actions + (size_t)(kdone + 1) * (slot_act / 4u), a_off);
         }
+#ifdef QG_PHASE_TIMES
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(a_in) : "memory");
+#endif
+        QG_MARK(2);                                                 // the action in a register
         const float aclip = fminf(fmaxf(a_in, -1.f), 1.f);         // quadruped.py:160
         J.u = fminf(fmaxf(aclip, clo), chi);
         quat_unit(B);
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
 #pragma unroll 1
         for (int s = 0; s < fs; ++s) substep_link<BAKED>(C, cm, sm, r, lead_env, B, J, K, s == fs - 1, srow, k, zaxis_z);
         nstep += fs;
+        QG_MARK(3);                                                 // physics done
 
         const float ssq = env_sum(r < 3 ? aclip * aclip : 0.f);
         const float c_fwd = Tk.w_forward * B.vw.x;
@@ -240,6 +247,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             }
         }
         wave_sync();                    // the tile's reads are done before the next env-step's last substep writes it again
+        QG_MARK(4);                                                 // terminations, reward, tile, row stores issued
         stepped = true;
         ++kdone;
         if constexpr (DOOR) {
@@ -281,15 +289,19 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
 // The ring: `count` more env-steps are rung (door += count unless the kernel has retired), then the caller's stream waits here until
 // every wave of the resident grid has reported them -- what follows on the stream (a policy) reads the step's rows.  One wave; lane
 // s < QG_RES_SHARDS watches arrival shard s.  nwaves = waves of the resident grid.
-__global__ __launch_bounds__(QGK_WAVE) void qg_resident_ring_kernel(KResident R, unsigned count, unsigned nwaves) {
+// `hint` = the door value the host expects (env-steps rung through the API so far): right in an eager loop, where it saves the ring a
+// load round trip in front of its compare-and-swap (0.4 us of the 0.8 the door took, phase clock); stale in a replayed graph, where
+// the first swap fails and returns the value to go on with.
+__global__ __launch_bounds__(QGK_WAVE) void qg_resident_ring_kernel(KResident R, unsigned count, unsigned nwaves, unsigned long long hint) {
     const int lane = threadIdx.x;
     unsigned long long target = 0;
     int ok = 0;
+    QG_MARK(8);                                                     // ring kernel entered
     if (lane == 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long v = __hip_atomic_load(R.door, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long v = hint;
         for (;;) {
-            if (!(v & QG_DOOR_STOP)) {      // the swap can only lose against a retiring wave (v gains STOP)
+            if (!(v & QG_DOOR_STOP)) {      // the swap can only lose against a stale hint or a retiring wave (v gains STOP)
                 if (__hip_atomic_compare_exchange_strong(R.door, &v, v + count, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { target = v + count; ok = 1; break; }
                 continue;
             }
@@ -307,13 +319,15 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_resident_ring_kernel(KResident R,
     }
     ok = __shfl(ok, 0);
     if (!ok) return;
+    QG_MARK(9);                                                     // door advanced
     target = ((unsigned long long)__shfl((unsigned)(target >> 32), 0) << 32) | (unsigned long long)(unsigned)__shfl((unsigned)target, 0);
     const unsigned long long members = lane < QG_RES_SHARDS && (unsigned)lane < nwaves ? (nwaves - lane + QG_RES_SHARDS - 1) / QG_RES_SHARDS : 0ull;
     const unsigned long long want = target * members;
     unsigned long long last = 0, t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
+    for (unsigned polls = 1;; ++polls) {
         const unsigned long long have = members ? __hip_atomic_load(R.done + 16 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         if (__all(have >= want)) break;
+        if (polls & 31u) continue;                                              // (the clock is a scalar memory read: not in every round)
         if (__any(have != last)) t0 = __builtin_amdgcn_s_memrealtime();        // an arrival: the waves are alive
         last = have;
         if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)R.ring_ticks) {
@@ -323,8 +337,8 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_resident_ring_kernel(KResident R,
             }
             break;
         }
-        __builtin_amdgcn_s_sleep(1);
     }
+    QG_MARK(10);                                                    // every shard has reported
 }
 
 // door control: op 0 sets STOP (the resident waves finish what is rung, store the state and exit), op 1 clears it (before the next launch)

@@ -79,6 +79,25 @@ def test_bench_prints_one_contract_line_on_one_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [["--seq", "16"], ["--resident", "ahead"], ["--resident", "closed"]])
+def test_bench_opt_in_forms_say_what_they_are(mode):
+    """The opt-in forms that keep the state in registers across env-steps print the same contract line, name themselves in
+    `config.workload`, restate the algorithmic bytes for the traffic they really do (action in, packed row out, state once per launch)
+    and never change the default line's keys."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "320", "--warmup", "32", "--no-cpu-baseline"] + mode,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert CONTRACT_KEYS <= set(d) and d["steps"] == 320 and d["state_finite"] is True
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "OPT-IN" in d["config"]["workload"] and "pool of 16" in d["config"]["workload"]
+    r = d["roofline"]
+    assert r["kernel"] == "qg_step_kernel_link_multi" and r["traffic"] is None
+    assert 188 <= r["algorithmic_bytes_per_env_step"] < 588        # 48 B in, 140 B out; + 448 / 16 B for a 16-step launch's state
+    assert 0.004 < d["ms_per_step"] < 0.03
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("envs_per_gpu", [512, 32768])
 def test_bench_two_ranks_rehearsal_on_one_gpu(envs_per_gpu):
     """The N > 1 code path of bench.py (rank-local shards, per-step gather, max-over-ranks timing, one line from rank 0),

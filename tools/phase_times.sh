@@ -9,7 +9,7 @@ if [ "${1:-build}" = build ]; then
     -o tools/lib_phase.so quadruped-gym_amd/csrc/qg_capi.hip -ldl
 else
   export QUADGYM_LIB=tools/lib_phase.so
-  python tools/phase_times.py plain 4096 4 && python tools/phase_times.py walking 4096 4 && python tools/phase_times.py po 4096 10 \
+  python tools/phase_times.py plain 4096 4 && python tools/phase_times_resident.py 4096 4 && python tools/phase_times.py walking 4096 4 && python tools/phase_times.py po 4096 10 \
     && python tools/phase_times.py plain 32768 4 && python tools/phase_times.py walking 32768 4 \
     && python tools/phase_times.py plain 12000 4 && python tools/phase_times.py walking 12000 4
 fi
