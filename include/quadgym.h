@@ -27,7 +27,8 @@
  * has gone to a caller's stream since the last one: their own stream is synchronised at the end
  * of every call, so there is nothing to wait for.  Once a device-pointer step of the handle has
  * been captured into a hipGraph the wait is taken on every host-pointer call: replays enqueue
- * steps the library does not see.)
+ * steps the library does not see.  Device-pointer steps on the legacy NULL stream must not overlap
+ * another stream's capture: the library cannot ask the NULL stream whether it is being captured.)
  *
  * Layouts at the boundary (row-major, env-major -- what NumPy / torch hand over):
  *   actions  [n_envs][12] f32      obs   [n_envs][obs_dim] f32
@@ -296,6 +297,12 @@ typedef struct qg_walk_params {
     double body_height;              /* :369    0.13 */
     double amp_target[QG_NU];        /* :279-285 [1.5, 0.5, 0] * 4 */
     double freq_target[QG_NU];       /* :272-277 [1, 1, 0] * 4 */
+    int32_t unit_zero;               /* 0 (default, the reference): unit() of an exactly zero vector is NaN (math_utils.py:7-8) and that
+                                        NaN reaches progress_direction_reward_local and the total (walking_quad.py:197-205,422);
+                                        1: the direction term is 0 when the local xy velocity or the commanded velocity is exactly
+                                        zero.  Why an option: the engine's f64 state practically never holds an exact zero there, this
+                                        f32 pipeline with its exact four-fold symmetry does on the first step of EVERY episode, and a
+                                        NaN reward poisons a PPO update (train_quadruped.py:132-134) -- INTEGRATION.md section 4 */
 } qg_walk_params;
 
 typedef struct qg_walk qg_walk;

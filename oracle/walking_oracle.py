@@ -172,7 +172,10 @@ class WalkingOracle:
     post_step() [input_control_reward on the step's sensordata and data.ctrl :352-421; flip termination
     :156-160]."""
 
-    def __init__(self, n, dt, settling_time=0.0, params=None):
+    def __init__(self, n, dt, settling_time=0.0, params=None, unit_zero=False):
+        # unit_zero: qg_walk_params.unit_zero of the product -- the direction term is 0 where either norm is exactly 0 instead of the
+        # reference's NaN (math_utils.py:7-8); False = the reference
+        self.unit_zero = bool(unit_zero)
         self.p = params or default_params()
         self.n, self.dt, self.settling = n, dt, settling_time
         self.controls = Controls(n)
@@ -213,6 +216,9 @@ class WalkingOracle:
         control_cost = p["control_cost_alpha"] * self.prev_ctrl_cost + (1 - p["control_cost_alpha"]) * cost
         with np.errstate(all="ignore"):
             direction = np.sum(unit(vel[:, :2]) * unit(cv[:, :2]), axis=1)                      # :197-201
+        if self.unit_zero:
+            zero = (np.linalg.norm(vel[:, :2], axis=1) == 0) | (np.linalg.norm(cv[:, :2], axis=1) == 0)
+            direction = np.where(zero, 0.0, direction)
         speed_cost = (np.linalg.norm(vel[:, :2], axis=1) - np.linalg.norm(cv[:, :2], axis=1)) ** 2   # :212-218
         heading = np.sum(xax[:, :2] * self.controls.heading[:, :2], axis=1)                     # :231-235
         orientation = zax[:, 2]                                                                  # :237-241

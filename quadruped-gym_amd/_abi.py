@@ -112,6 +112,7 @@ class QgWalkParams(C.Structure):
         ("body_height", C.c_double),
         ("amp_target", C.c_double * NU),
         ("freq_target", C.c_double * NU),
+        ("unit_zero", C.c_int32),
     ]
 
 

@@ -323,8 +323,14 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
     if (stream != s->stream) {
         s->caller_inflight = 1;
         if (!s->captured_once) {
+            // (not asked of the legacy NULL stream: while ANOTHER stream is in global-mode capture that query itself is a
+            // capture-implicit error and invalidates the capture in progress; a failed query counts as "captured")
             hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) s->captured_once = 1;
+            if (stream) {
+                const hipError_t qe = hipStreamIsCapturing(stream, &cs);
+                if (qe != hipSuccess) { (void)hipGetLastError(); s->captured_once = 1; }
+                else if (cs == hipStreamCaptureStatusActive) s->captured_once = 1;
+            }
         }
     }
     if (po && !(walk && po_fusable(s))) return fail(QG_ERR_ARG, "launch_step: no step kernel with the fused observation pack for this handle");
@@ -1075,14 +1081,15 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
     k.inv_dt = (float)(1.0 / dt);
     int64_t settle = params->settling_time > 0 ? qg_time_limit_substeps_impl(s->model.timestep, params->settling_time) : 0;
     k.settle_substeps = (int32_t)(settle > INT32_MAX ? INT32_MAX : settle);
-    k.window = (int32_t)std::ceil(2.0 / (params->min_freq * dt));   // math_utils.py:26-28
     {   // the reference puts no upper bound on the window (frame_skip 1 / 2 / 3 at the shipped timestep: 1000 / 500 / 334 samples);
-        // only memory does: the ring holds window x 12 x n_envs samples
-        const double w_exact = std::ceil(2.0 / (params->min_freq * dt));
+        // only memory does: the ring holds window x 12 x n_envs samples.  (Checked as a double BEFORE the conversion: a tiny min_freq
+        // would make the cast itself undefined.)
+        const double w_exact = std::ceil(2.0 / (params->min_freq * dt));   // math_utils.py:26-28
         if (!(w_exact >= 1) || w_exact > 1e6) {
             delete w;
             return fail(QG_ERR_ARG, "qg_walk_create: estimator window %g outside 1..1000000 samples (min_freq * timestep * frame_skip)", w_exact);
         }
+        k.window = (int32_t)w_exact;
     }
     k.ema_alpha = (float)params->ema_alpha;
     k.control_cost_alpha = (float)params->control_cost_alpha;
@@ -1095,6 +1102,7 @@ extern "C" int qg_walk_create(qg_sim *s, const qg_walk_params *params, qg_walk *
         k.freq_target[i] = (float)params->freq_target[i];
     }
     k.auto_reset = s->task.auto_reset;
+    k.unit_zero = params->unit_zero ? 1 : 0;
     const size_t n = (size_t)s->n, W = (size_t)k.window;
 #define WALLOC(ptr, bytes)                                                                   \
     do {                                                                                    \
@@ -1470,15 +1478,16 @@ extern "C" int qg_po_create(qg_walk *w, int32_t obs_window, qg_po **out) {
     hipError_t e = hipMalloc((void **)&p->st.orient, 4 * n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.alias, n);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.nstep, n * 4);
-    // the ring keeps every frame twice (KPoState.stack); 64 bytes of slack: the fused forms' unpredicated 16-byte loads may read past a row
-    if (e == hipSuccess) e = hipMalloc((void **)&p->st.stack, 2 * n * width * 4 + 64);
+    // the ring keeps every frame twice (KPoState.stack); QG_PO_RING_SLACK bytes behind it: the fused forms' unpredicated 16-byte loads may
+    // read that far past the last env's row (sized and asserted against the copy's batch shape next to QG_PO_COPY_K)
+    if (e == hipSuccess) e = hipMalloc((void **)&p->st.stack, 2 * n * width * 4 + QG_PO_RING_SLACK);
     if (e == hipSuccess) e = hipMalloc((void **)&p->st.head, n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_obs33, n * QG_NSENSOR * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_out, n * width * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_term, n * width * 4);
     if (e == hipSuccess) e = hipMemset(p->st.alias, 0, n);
     if (e == hipSuccess) e = hipMemset(p->st.nstep, 0, n * 4);
-    if (e == hipSuccess) e = hipMemset(p->st.stack, 0, 2 * n * width * 4 + 64);
+    if (e == hipSuccess) e = hipMemset(p->st.stack, 0, 2 * n * width * 4 + QG_PO_RING_SLACK);
     if (e == hipSuccess) e = hipMemset(p->st.head, 0, n * 4);
     if (e == hipSuccess) {                                           // computed_orientation = [1, 0, 0, 0] (:19)
         float *h = new float[4 * n];

@@ -66,6 +66,8 @@ DEV V3 env_sum(V3 a) { return v3(env_sum(a.x), env_sum(a.y), env_sum(a.z)); }
 #define QG_T_L2(g) QG_T_ROR("a" g, "a" g, "0x3") QG_T_ROR("a" g, "c" g, "0xc")
 #define QG_T_Q1(g) QG_T_QP("a" g, "[1,0,3,2]")
 #define QG_T_Q2(g) QG_T_QP("a" g, "[2,3,0,1]")
+// (every output is TIED, "+v": an input-output operand can never be allocated on top of one of the plain inputs b / d, which is what
+// an early-clobber marker would otherwise have to say -- a and c are read before and written by the block, b and d only read)
 #define QG_T_OUT(g, v) [a##g] "+v"(v[4 * g]), [c##g] "+v"(v[4 * g + 2])
 #define QG_T_IN(g, v) [b##g] "v"(v[4 * g + 1]), [d##g] "v"(v[4 * g + 3])
 DEV void env_sum_banked16(float (&v)[16]) {
@@ -492,7 +494,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
                 if (lead_env) hw = walk_env_load(WK.S, n, env);
                 const float hx = __shfl(hw.hx, lane & ~15), hy = __shfl(hw.hy, lane & ~15);
                 const PoEnvIn pin = po_env_load(PK.S, n, env);
-                __syncthreads();
+                __syncthreads();      // THE barrier of this role (helper, PO): its partner is the physics waves' __syncthreads() behind
+                                      // their auto-reset block.  Every wave of the workgroup passes exactly one barrier on every path;
+                                      // a second one in either role, or a return in front of it, deadlocks the workgroup.
                 const int le = 4 * wave + el;
                 if (live)
                     po_frame_env16(PK.P, PK.S, n, env, lane & 15, lead_env, pin, tile + el * 35, s_hand[le][1], s_hand[le][2], s_hand[le][3],
@@ -501,7 +505,9 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
                 po_emit_new(PK.P, PK.S, n, blockIdx.x * QG_PO_ENVS, le, lane & 15, s_new, s_rst, s_slot, s_fin, PK.out, PK.term_out);
                 return;
             }
-            __syncthreads();      // the one barrier of the workgroup: behind it the physics waves write what this wave read at entry
+            __syncthreads();      // the one barrier of the workgroup (helper role without the observation pack; partner: the physics
+                                  // waves' __syncthreads() behind their auto-reset block): behind it the physics waves write what this
+                                  // wave read at entry.  Exactly one barrier per wave on every path -- see the note at the other site.
             if constexpr (RWDH) {
                 // the reward of the step, on the sensor tile the physics wave has finished (LDS), while that wave stores the state
                 // and writes the observation rows
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
                 if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }   // (the tile is final before the helper reads it)
             }
         }
-        __syncthreads();
+        __syncthreads();          // partner of the helper waves' one barrier (either of its two sites above)
         if constexpr (!RWDH) {
             wf[0] = s_est[wave][lane][0];
             wa[0] = s_est[wave][lane][1];

@@ -1120,6 +1120,11 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
 
 #define QGK_QUAD_ENVS 16    // envs per wave in the one-leg-per-lane kernel
 #define QG_PO_COPY_K 4      // 16-byte groups per lane and substep of the fused observation pack's history copy (po_row_copy_*)
+// po_row_copy_load issues its K loads unpredicated: the last batch of a row may read up to (K - 1) * LPE groups + one group past the
+// lane's share, i.e. past the end of the LAST env's doubled ring for some (window, rotation) pairs -- windows 8, 13, 18, 40, 45, ...
+// (round-3 advisor; the 64 bytes of slack the ring used to have covered the windows the tests ran).  The ring is allocated with
+// QG_PO_RING_SLACK bytes behind it; the largest LPE of the wave-level fused forms is 4 (one leg per lane).
+static_assert((QG_PO_COPY_K - 1) * 4 * 16 + 16 <= QG_PO_RING_SLACK, "frame-ring slack against po_row_copy_load's over-read");
 // Epilogue of the observation pack fused into a kernel whose wave owns ENVS consecutive envs with LPE lanes each (a lane owns NCH =
 // 12 / LPE control channels, `aclip` = this step's env-clipped actions of those): the lanes put data.ctrl into the frame, the env's lead
 // lane runs the orientation filter on the sensor row `srow` the wave has staged in LDS and builds the frame (po_frame_env: the
@@ -1243,6 +1248,9 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
                 if (slot >= PK.P.window) slot = 0;
                 if (PK.P.window > 1) po_copy_history_now<4>(PK.P, PK.S, (size_t)env * (PK.P.window * QG_PO_FRAME), slot, k, PK.out, live);
             }
+            // (partner: the physics waves' __syncthreads() behind their auto-reset block, "partner of the helper waves' one barrier"
+            // below.  Exactly one barrier per wave on every path: a second one in either role, or a return in front of it, deadlocks
+            // the workgroup -- and on this pool a hung workgroup is a hung GPU.)
             __syncthreads();      // the one barrier of the workgroup: behind it the physics waves read s_est and write what this wave read
             if constexpr (RWDH) {
                 // the reward of the step, on the sensor tile the physics wave has finished (LDS), while that wave goes on with the resets and
@@ -1525,7 +1533,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
             // them); from here on this wave may overwrite what the helper read at entry (data.ctrl, the episode counter), and (RWDH)
             // the helper evaluates the reward on the finished sensor tile
             if constexpr (RWDH) { if (k_e == 0) s_done[wave][lane >> 2] = done ? 1.f : 0.f; }
-            __syncthreads();
+            __syncthreads();      // partner of the helper waves' one barrier
             if constexpr (!RWDH) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { wf[i] = s_est[wave][lane][i]; wa[i] = s_est[wave][lane][3 + i]; }

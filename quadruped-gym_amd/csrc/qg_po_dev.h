@@ -256,6 +256,7 @@ typedef float PoF4 __attribute__((ext_vector_type(4), aligned(4)));
 // The first 80 groups (five per lane: a whole row up to window 12) are LOADED in the prologue and STORED after the substep loop
 // (po_copy_history_store), so that the copy's memory round trip runs under the physics instead of in front of it; longer rows copy
 // the rest on the spot.
+#define QG_PO_RING_SLACK 256   // bytes allocated behind the frame ring (see the static_assert next to QG_PO_COPY_K, qg_kernels.hip)
 #define QG_PO_HIST_K 5
 struct PoHistRegs { PoF4 v[QG_PO_HIST_K]; };
 __device__ __forceinline__ const char *po_hist_src(const KPoParams &P, const KPoState &S, size_t row, int slot) {

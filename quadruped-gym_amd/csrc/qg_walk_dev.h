@@ -33,6 +33,7 @@ struct KWalkParams {
     int32_t cmd_sample;
     uint32_t cmd_fixed;
     float cmd_min_speed, cmd_max_speed, cmd_theta, cmd_alpha, cmd_speed;
+    int32_t unit_zero;           // 1: unit() of an exactly zero vector makes the direction term 0 instead of the reference's NaN
 };
 
 struct KWalkState {
@@ -432,6 +433,11 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
                                                 const WalkEnvIn &in, bool finished, float *__restrict__ reward,
                                                 float *__restrict__ comps /* [n][11] or NULL */, int sample_here, uint64_t seed,
                                                 uint64_t env_index_base) {
+    // No multiply-add contraction in here: every product and sum below rounds on its own, as in the reference's NumPy expressions --
+    // and, what matters on the device, the same way in EVERY kernel this function is inlined into.  Left to the backend, a*b + c*d
+    // became fma(a, b, c*d) in one kernel and fma(c, d, a*b) in another (the helper wave of the walking launch against the physics
+    // wave of the fused observation-pack launch: rewards one ulp of their largest term apart, round 3).  One lane per env runs this.
+#pragma clang fp contract(off)
     const float px = s[18], py = s[19], pz = s[20];                  // body_pos
     const float xax = s[24], xay = s[25];                            // body_xaxis
     const float zaz = s[29];                                         // body_zaxis z
@@ -452,9 +458,11 @@ __device__ __forceinline__ void walk_reward_env(const KWalkParams &P, const KWal
     // -ffinite-math-only, under which 0/0 is formally undefined, so the documented NaN is produced explicitly: the
     // division is guarded and the quiet-NaN bit pattern is stored through integer selects below.
     const float nv = walk_sqrt(vx * vx + vy * vy), nc = walk_sqrt(cvx * cvx + cvy * cvy);
-    const bool degenerate = (nv == 0.f) || (nc == 0.f);
-    const float dv = degenerate ? 1.f : nv, dc = degenerate ? 1.f : nc;
+    const bool zero_norm = (nv == 0.f) || (nc == 0.f);
+    const bool degenerate = zero_norm && !P.unit_zero;              // qg_walk_params.unit_zero = 1: the direction term is 0 there instead
+    const float dv = zero_norm ? 1.f : nv, dc = zero_norm ? 1.f : nc;
     const float direction = (vx * cvx + vy * cvy) * walk_rcp(dv * dc);   // = unit(v) . unit(c): one reciprocal instead of four divisions
+                                                                         // (a zero norm means a zero numerator: 0 * 1 = 0)
     const float dsp = nv - nc;
     const float speed_cost = dsp * dsp;
     const float heading = xax * hx + xay * hy;                       // :231-235

@@ -68,7 +68,7 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
 
     def __init__(self, num_envs, settling_time=0, random_controls=False, random_init=False, reset_options=None,
                  model_path="builtin", max_time=10.0, frame_skip=4, device=0, env_index_base=0, seed=0, walk_params=None,
-                 device_commands=False, auto_reset=True, use_default_termination=True, infos_mode="lazy"):
+                 device_commands=False, auto_reset=True, use_default_termination=True, infos_mode="lazy", nan_direction=True):
         if infos_mode not in ("lazy", "finished"):
             raise ValueError("infos_mode must be 'lazy' (every env's component dict, built when touched) or 'finished' (content "
                              "for the envs that finished only; `last_components` holds every env's components as one array)")
@@ -93,6 +93,12 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
         self._lib = _abi.load_library()
         self.params = walk_params if walk_params is not None else default_walk_params()
         self.params.settling_time = float(settling_time)
+        # nan_direction=True is the reference: unit() of an exactly zero local velocity (or command) is NaN and so are the direction
+        # term and the reward of that step (math_utils.py:7-8, walking_quad.py:197-205).  In this f32 pipeline the local xy velocity is
+        # EXACTLY zero on the first step of every episode, so a training run wants False: the term is 0 there.
+        self.nan_direction = bool(nan_direction)
+        if not self.nan_direction:
+            self.params.unit_zero = 1
         h = C.c_void_p()
         check(self._lib.qg_walk_create(self._sim._h, C.byref(self.params), C.byref(h)), "qg_walk_create")
         self._w = h
@@ -131,27 +137,46 @@ class WalkingQuadrupedVecEnv(_VecEnvBase):      # SB3's VecEnv where that packag
         and, for the partially observable env, the filter estimate and the frame ring -- as a ``dict`` of NumPy arrays.
         ``restore(snapshot)`` on an env of the same shape continues bit for bit."""
         snap = {"sim": self._sim.snapshot()}
-        blob = np.empty(int(self._lib.qg_walk_state_bytes(self._w)), np.uint8)
+        blob = np.empty(self._blob_bytes(self._lib.qg_walk_state_bytes, self._w, "qg_walk_state_bytes"), np.uint8)
         check(self._lib.qg_walk_get_state(self._w, blob.ctypes.data), "qg_walk_get_state")
         snap["walk"] = blob
         if getattr(self, "_po", None):
-            pblob = np.empty(int(self._lib.qg_po_state_bytes(self._po)), np.uint8)
+            pblob = np.empty(self._blob_bytes(self._lib.qg_po_state_bytes, self._po, "qg_po_state_bytes"), np.uint8)
             check(self._lib.qg_po_get_state(self._po, pblob.ctypes.data), "qg_po_get_state")
             snap["po"] = pblob
         snap["velocity"], snap["heading"] = self.velocity.copy(), self.heading.copy()
         return snap
 
+    def _blob_bytes(self, fn, handle, what):
+        nbytes = int(fn(handle))
+        if nbytes <= 0:                   # the C side reports errors as small negative numbers
+            check(nbytes if nbytes < 0 else -1, what)
+        return nbytes
+
     def restore(self, snap):
-        self._sim.restore(snap["sim"])
+        """All-or-nothing: every part of the snapshot is checked against this env BEFORE anything is written.  Continues bit for
+        bit with ``device_commands=True`` (or fixed commands); with host-side command sampling the commands an auto-reset re-draws
+        come from NumPy's global generator, which a snapshot does not hold."""
+        po = getattr(self, "_po", None)
         blob = np.ascontiguousarray(snap["walk"], dtype=np.uint8)
-        if blob.size != int(self._lib.qg_walk_state_bytes(self._w)):
+        if blob.size != self._blob_bytes(self._lib.qg_walk_state_bytes, self._w, "qg_walk_state_bytes"):
             raise ValueError("the snapshot was taken from an env of another shape (num_envs / estimator window)")
-        check(self._lib.qg_walk_set_state(self._w, blob.ctypes.data), "qg_walk_set_state")
-        if getattr(self, "_po", None):
+        pblob = None
+        if po:
+            if "po" not in snap:
+                raise ValueError("the snapshot holds no observation-pack state (it was taken from an env without one)")
             pblob = np.ascontiguousarray(snap["po"], dtype=np.uint8)
-            if pblob.size != int(self._lib.qg_po_state_bytes(self._po)):
+            if pblob.size != self._blob_bytes(self._lib.qg_po_state_bytes, po, "qg_po_state_bytes"):
                 raise ValueError("the snapshot was taken from an env of another shape (num_envs / obs_window)")
-            check(self._lib.qg_po_set_state(self._po, pblob.ctypes.data), "qg_po_set_state")
+        sim = snap["sim"]
+        if np.asarray(sim["qpos"]).shape != (self.num_envs, 19) or np.asarray(sim["episode"]).shape != (self.num_envs,):
+            raise ValueError("the snapshot was taken from an env of another size")
+        if np.asarray(snap["velocity"]).shape != self.velocity.shape or np.asarray(snap["heading"]).shape != self.heading.shape:
+            raise ValueError("the snapshot's commands do not fit this env")
+        self._sim.restore(sim)
+        check(self._lib.qg_walk_set_state(self._w, blob.ctypes.data), "qg_walk_set_state")
+        if po:
+            check(self._lib.qg_po_set_state(po, pblob.ctypes.data), "qg_po_set_state")
         self.velocity[:], self.heading[:] = snap["velocity"], snap["heading"]
 
     def _resample(self, idx):

@@ -75,3 +75,23 @@ def test_reward_stack_bookkeeping():
     assert np.array_equal(o.prev_ctrl_cost, c0)
     o.reset(mask=[True, False, False])
     assert np.isnan(o.prev_derive[0]) and not np.isnan(o.prev_derive[1]) and (o.ideal[0] == 0).all()
+
+
+def test_unit_of_a_zero_vector_is_nan_unless_the_option_says_zero():
+    """math_utils.unit() (math_utils.py:7-8) divides by a zero norm: NaN in the direction term and in the total
+    (walking_quad.py:197-205,422) -- kept by default.  ``unit_zero=True`` is the product's qg_walk_params.unit_zero: the direction
+    term is 0 where either norm is exactly 0, every other component and every other env is untouched."""
+    sens = np.zeros((3, 33)); sens[:, 29] = 1.0; sens[:, 24] = 1.0; sens[:, 20] = 0.12
+    sens[0, 30:32] = [0.2, -0.1]          # env 0: moving body, zero command
+    sens[2, 30:32] = [0.2, -0.1]          # env 2: moving body, command below; env 1: body at rest, command below
+    out = {}
+    for uz in (False, True):
+        o = W.WalkingOracle(3, 0.008, unit_zero=uz)
+        o.controls.velocity[1:, :2] = [0.3, 0.1]
+        out[uz] = o.post_step(sens, np.tile([0, 0, -0.5] * 4, (3, 1)))
+    (t0, c0, _), (t1, c1, _) = out[False], out[True]
+    assert np.isnan(c0[:2, 2]).all() and np.isnan(t0[:2]).all() and np.isfinite(t0[2])
+    assert (c1[:2, 2] == 0).all() and np.isfinite(t1).all()
+    others = np.delete(np.arange(11), 2)
+    assert np.array_equal(c0[:, others], c1[:, others]) and c0[2, 2] == c1[2, 2] and t0[2] == t1[2]
+    assert np.allclose(t1, c1.sum(1))
