@@ -178,6 +178,34 @@ def step(model, task, env, action, limit_substeps=None):
     return obs, rew.value, bool(done.value), comps
 
 
+def contact_census(model, frame_skip, qpos, qvel, act, nstep, actions, extra=1):
+    """bool [n][frame_skip + extra][13]: which bodies are in ground contact (contact_W > 0 in the oracle's diagnostics) in every substep
+    of ONE env-step from this state, and in `extra` substeps beyond it (same action)."""
+    qpos, qvel, act = np.asarray(qpos, np.float64), np.asarray(qvel, np.float64), np.asarray(act, np.float64)
+    ctrl = np.clip(np.asarray(actions, np.float64), -1.0, 1.0)            # quadruped.py:160
+    n, steps = len(qpos), int(frame_skip) + int(extra)
+    out = np.zeros((n, steps, NBODY), bool)
+    for i in range(n):
+        e = Env()
+        e.qpos[:] = qpos[i].tolist(); e.qvel[:] = qvel[i].tolist(); e.act[:] = act[i].tolist()
+        e.nstep = int(nstep[i])
+        for k in range(steps):
+            _, dg = substep(model, e, ctrl[i], want_diag=True)
+            out[i, k] = [w > 0.0 for w in dg.contact_W]
+    return out
+
+
+def contact_switch_near_sensors(model, frame_skip, qpos, qvel, act, nstep, actions, before=2):
+    """For each env: does the set of bodies in ground contact change around the substep the step's sensors describe -- the LAST one
+    (mj_step computes sensors before it integrates) -- i.e. between substeps frame_skip - 1 - before .. frame_skip (one beyond the step)?
+    A touch-down or lift-off there lands one substep earlier or later in f32 than in f64, and the accelerometer, which reads that
+    substep's contact force, jumps; the parity tests hold those states to a looser bound and every other state to a tight one."""
+    c = contact_census(model, frame_skip, qpos, qvel, act, nstep, actions, extra=1)
+    lo = max(0, int(frame_skip) - 1 - int(before))
+    win = c[:, lo:]
+    return (win != win[:, :1]).any(axis=(1, 2))
+
+
 class Batch:
     """n independent oracle envs stepped in C (env-major arrays)."""
 

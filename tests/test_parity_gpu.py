@@ -23,6 +23,24 @@ TOL = {
     "A": dict(qpos=(5e-6, 2e-6), qvel=(2e-3, 1e-4), act=(4e-7, 1e-6), obs=(3.5e-4, 1e-4), accel=(0.025, 1e-3), reward=(1.5e-5, 1e-5)),
     "B": dict(qpos=(4e-4, 1e-4), qvel=(5e-2, 2e-2), act=(6e-7, 1e-6), obs=(3e-3, 2e-3), accel=(2.0, 5e-2), reward=(1.5e-3, 1e-3)),
 }
+# frame_skip 20, accelerometer (round 4): the 2.0 m/s^2 above is set by the handful of states where a contact switches inside the
+# step -- a body touches down or lifts off at a slightly different substep in f32 and the reading of the last substep jumps.  States
+# whose contact census (the oracle's contact_W > 0 per body) does NOT change around the substep the sensors describe (the last one and
+# two before it, one after: oracle.contact_switch_near_sensors) are held to this bound instead; the loose one only covers the rest.
+ACCEL_B_STEADY = (0.01, 1e-3)        # measured: 4.2e-4 on the golden states (every mapping), 1.7e-3 on config 5's 4096-env sample
+
+
+def close_accel_b(oracle, got, ref, model, frame_skip, state, actions, keep=None):
+    qpos, qvel, act, nstep = state
+    changed = oracle.contact_switch_near_sensors(model, frame_skip, qpos, qvel, act, nstep, actions)
+    if keep is not None:
+        got, ref, changed = got[keep], ref[keep], changed[keep]
+    steady = ~changed
+    assert steady.sum() >= 20, "enough states keep their contacts around the sensor substep"
+    worst = close(got[steady], ref[steady], ACCEL_B_STEADY, "accelerometer (contact census steady)")
+    if changed.any():
+        close(got[changed], ref[changed], TOL["B"]["accel"], "accelerometer (a contact switches inside the step)")
+    return worst, int(changed.sum())
 
 
 def configure(task, case):
@@ -57,7 +75,7 @@ MAPPINGS = {"lane": _abi.MAP_LANE, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR,
 
 @pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
 @pytest.mark.parametrize("case", ["A", "B"])
-def test_step_matches_golden_vectors(gold, case, mapping):
+def test_step_matches_golden_vectors(oracle, gold, case, mapping):
     """Every work mapping of the step kernel (one env per lane / one leg per lane / two legs per lane) against the fixture."""
     from quadruped_gym_amd.sim import BatchedSim
     task = configure(_abi.default_task(), case)
@@ -79,7 +97,12 @@ def test_step_matches_golden_vectors(gold, case, mapping):
     mask = np.ones(obs.shape[1], bool)
     mask[sl] = False
     close(obs[:, mask], g("obs")[:, mask], t["obs"], "obs")
-    close(obs[:, sl], g("obs")[:, sl], t["accel"], "accelerometer")
+    if case == "B":
+        worst, nsw = close_accel_b(oracle, obs[:, sl], g("obs")[:, sl], oracle.default_model(), task.frame_skip,
+                                   (gold["qpos"], gold["qvel"], gold["act"], gold["nstep"]), gold["actions"])
+        print(f"frame_skip 20 accelerometer, {mapping}: worst error on steady-contact states {worst:.3e}, {nsw} states switch a contact")
+    else:
+        close(obs[:, sl], g("obs")[:, sl], t["accel"], "accelerometer")
     close(rew, g("reward"), t["reward"], "reward")
     close(comps, g("comps"), t["reward"], "reward components")
     # terminations are threshold tests on f32 vs f64 states: identical except within rounding of the threshold
@@ -742,7 +765,9 @@ def test_config5_at_full_size_invariants_and_oracle_sample(oracle):
     T = TOL["B"]
     jp = np.r_[0:12, 15:21]                                         # joint positions, gyro, velocimeter
     assert np.allclose(obs[idx][keep][:, jp], obs_o[keep][:, jp], atol=T["obs"][0], rtol=T["obs"][1])
-    assert np.allclose(obs[idx][keep][:, 12:15], obs_o[keep][:, 12:15], atol=T["accel"][0], rtol=T["accel"][1])
+    worst, nsw = close_accel_b(oracle, obs[idx][:, 12:15], obs_o[:, 12:15], oracle.default_model(), fs,
+                               (qpos[idx], qvel[idx], act[idx], nstep[idx]), a[idx], keep=keep)
+    print(f"config 5 accelerometer: worst error on steady-contact states {worst:.3e}, {nsw} of {int(keep.sum())} states switch a contact")
     assert np.allclose(rew[idx][keep], rew_o[keep], atol=T["reward"][0], rtol=T["reward"][1])
     q1 = sim.get_state()[0]
     assert np.allclose(q1[idx][keep], batch.get_state()[0][keep], atol=T["qpos"][0], rtol=T["qpos"][1])
