@@ -146,6 +146,9 @@ const char *qg_version(void);
  * committed profiles with it; bench.py flags a roofline entry that was measured on other sources (roofline.profile_stale). */
 const char *qg_build_id(void);
 const char *qg_last_error(void);
+/* PCI bus id ("0000:05:00.0") of HIP device `device_id` into out[len >= 16] -- what bench.py's N > 1 line lists per rank, so that
+ * "did RCCL see N ranks on N distinct GPUs" can be read off the line. */
+int qg_device_pci_bus_id(int32_t device_id, char *out, int32_t len);
 
 /* Fill with the constants compiled from the reference model (include/qg_model_data.h). */
 int qg_default_model(qg_model *out);

@@ -158,6 +158,7 @@ def load_library():
     lib.qg_build_id.argtypes = []
     lib.qg_last_error.restype = C.c_char_p
     lib.qg_last_error.argtypes = []
+    lib.qg_device_pci_bus_id.argtypes = [C.c_int32, C.c_char_p, C.c_int32]
     lib.qg_default_model.argtypes = [C.POINTER(QgModel)]
     lib.qg_default_task.argtypes = [C.POINTER(QgTask)]
     lib.qg_time_limit_substeps.restype = C.c_int64
@@ -229,7 +230,7 @@ def load_library():
 
 # every symbol include/quadgym.h declares
 EXPORTS = (
-    "qg_version", "qg_build_id", "qg_last_error", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
+    "qg_version", "qg_build_id", "qg_last_error", "qg_device_pci_bus_id", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
     "qg_step_device_packed", "qg_get_state", "qg_step_mirror", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_debug_phase_times", "qg_set_task", "qg_get_task",
     "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",

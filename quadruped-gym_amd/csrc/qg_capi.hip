@@ -52,7 +52,8 @@ struct qg_sim {
     int32_t creating;
     int32_t walk_bound;       // qg_walk layers bound to this handle (qg_set_task refuses while > 0)
     int32_t po_unfused;       // env QG_PO_UNFUSED=1: keep the observation pack of qg_po_step a launch of its own (A/B, parity test)
-    int32_t quad_wpe;         // development override of the quad kernel's register cap (waves per SIMD), env QG_QUAD_WPE; 0 = policy
+    int32_t simds;            // SIMDs of the handle's GPU (hipDeviceProp: compute units x 4; 1024 on an MI355X): AUTO's thresholds are
+                              // "one wave per SIMD" sizes
     // resident form of the one-link-per-lane step (qg_resident_*, qg_kernel_resident.hip)
     struct {
         int32_t active;       // qg_resident_start has set the mailbox up (the mode is on until qg_resident_stop)
@@ -93,6 +94,13 @@ extern "C" const char *qg_version(void) { return "quadgym 0.1.0 (gfx950)"; }
 #endif
 extern "C" const char *qg_build_id(void) { return QG_SOURCE_HASH; }
 extern "C" const char *qg_last_error(void) { return g_err; }
+
+extern "C" int qg_device_pci_bus_id(int32_t device_id, char *out, int32_t len) {
+    if (!out || len < 16) return qg_fail(QG_ERR_ARG, "qg_device_pci_bus_id: need a buffer of at least 16 bytes");
+    hipError_t e = hipDeviceGetPCIBusId(out, len, device_id);
+    if (e != hipSuccess) return qg_fail(QG_ERR_DEVICE, "hipDeviceGetPCIBusId(%d): %s", device_id, hipGetErrorString(e));
+    return QG_OK;
+}
 
 extern "C" int qg_default_model(qg_model *out) {
     if (!out) return fail(QG_ERR_ARG, "qg_default_model: null output");
@@ -173,11 +181,11 @@ extern "C" int qg_create(int32_t n_envs, int32_t device_id, const qg_model *mode
     s->track_ctrl = 1;
     { const char *e = getenv("QG_LINK_HELPERS"); s->link_helpers = e ? (atoi(e) != 0) : 1; }
     s->mapping = QG_MAP_AUTO;
-    if (const char *e = getenv("QG_PO_UNFUSED")) s->po_unfused = atoi(e) != 0;
-    if (const char *e = getenv("QG_QUAD_WPE")) {
-        int v = atoi(e);
-        s->quad_wpe = (v >= 1 && v <= 4) ? v : 0;
+    {
+        hipDeviceProp_t prop;
+        s->simds = (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) ? 4 * prop.multiProcessorCount : 1024;
     }
+    if (const char *e = getenv("QG_PO_UNFUSED")) s->po_unfused = atoi(e) != 0;
     {
         static const KModel baked = {QG_BAKED_FLOATS};
         s->baked = QG_BAKED_LEGS_IDENTICAL && memcmp(&km, &baked, sizeof km) == 0;
@@ -276,9 +284,11 @@ static int effective_mapping(const qg_sim *s) {
     if (s->mapping == QG_MAP_PAIR) return s->baked ? QG_MAP_PAIR : QG_MAP_QUAD;
     // (the one-link-per-lane kernel addresses the state with 32-bit byte offsets from scalar bases: 19 n floats must stay below 4 GiB)
     if (s->mapping == QG_MAP_LINK) return (s->task.sensor_lag && s->n <= (1 << 24)) ? QG_MAP_LINK : QG_MAP_QUAD;
-    // up to 4096 envs: 1024 waves of the one-link-per-lane kernel = one per SIMD
-    if (s->task.sensor_lag && s->n <= 1024 * QGK_LINK_ENVS) return QG_MAP_LINK;
-    if (s->baked && s->n > 1024 * QGK_QUAD_ENVS && (s->n <= 1024 * QGK_PAIR_ENVS || s->n >= 1792 * QGK_PAIR_ENVS)) return QG_MAP_PAIR;
+    // up to one wave of the one-link-per-lane kernel per SIMD (4096 envs on the 1024 SIMDs of an MI355X); the other boundaries are
+    // the same measurement in units of "waves per SIMD" (pair: > 1 quad wave per SIMD up to 1 pair wave per SIMD, and from 1.75 on)
+    const int simds = s->simds;
+    if (s->task.sensor_lag && s->n <= simds * QGK_LINK_ENVS) return QG_MAP_LINK;
+    if (s->baked && s->n > simds * QGK_QUAD_ENVS && (s->n <= simds * QGK_PAIR_ENVS || s->n >= (simds + 3 * (simds / 4)) * QGK_PAIR_ENVS)) return QG_MAP_PAIR;
     return QG_MAP_QUAD;
 }
 
@@ -288,11 +298,10 @@ static int effective_mapping(const qg_sim *s) {
 static bool po_fusable(const qg_sim *s) {
     const int emap = effective_mapping(s);
     if (emap == QG_MAP_LINK) return true;
-    if (emap == QG_MAP_PAIR) return (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS > 256;
+    if (emap == QG_MAP_PAIR) return (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS > s->simds / 4;
     if (emap == QG_MAP_QUAD) {
         const int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
-        const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
-        return qblocks > 256 && wpe <= 2;
+        return qblocks > s->simds / 4;
     }
     return false;
 }
@@ -351,18 +360,18 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
         if (po)
             hipLaunchKernelGGL((qg_step_kernel_pair<4, true, true>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, *walk, *po);
-        else if (pblocks > 256)
+        else if (pblocks > s->simds / 4)
             hipLaunchKernelGGL((qg_step_kernel_pair<4, true>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, *walk, KPoNone{});
         else
             hipLaunchKernelGGL((qg_step_kernel_pair<1, true>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, *walk, KPoNone{});
     } else if (walk) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
-        const int wpe = s->quad_wpe ? s->quad_wpe : (qblocks <= 1024 ? 1 : 2);
-        const bool wg4 = qblocks > 256;             // four-wave workgroups for grids of more than 256 waves
+        const int wpe = qblocks <= s->simds ? 1 : 2;
+        const bool wg4 = qblocks > s->simds / 4;    // four-wave workgroups for grids of more than one wave per compute unit
         dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
         if (po) {                                   // po_fusable(): four-wave workgroups, register cap for one or two waves per SIMD
             if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
-            else if (wpe == 1 && s->link_helpers && !s->quad_wpe)
+            else if (wpe == 1 && s->link_helpers)
                 hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, true, true>), g4, dim3(QGK_WAVE * 8), 0, stream, s->d_model, s->d_task, P, *walk, *po);
             else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
             else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, true>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, *po);
@@ -371,7 +380,7 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, false, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
         } else if (wpe == 1) {
             // at most one physics wave per SIMD: helper waves beside them (QG_LINK_HELPERS, as for the one-link-per-lane kernel)
-            if (s->link_helpers && !s->quad_wpe)
+            if (s->link_helpers)
                 hipLaunchKernelGGL((qg_step_kernel_quad<2, true, true, 4, false, true>), g4, dim3(QGK_WAVE * 8), 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else if (wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
             else hipLaunchKernelGGL((qg_step_kernel_quad<1, true, true, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, *walk, KPoNone{});
@@ -386,23 +395,21 @@ static int launch_step(qg_sim *s, const float *d_actions, float *d_obs, float *d
         else hipLaunchKernelGGL((qg_step_kernel_link<false, false, false>), lg, lb, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
     } else if (emap == QG_MAP_PAIR) {
         int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
-        if (pblocks > 256)
+        if (pblocks > s->simds / 4)
             hipLaunchKernelGGL((qg_step_kernel_pair<4, false>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, stream, s->d_task, P, KWalkNone{}, KPoNone{});
         else
             hipLaunchKernelGGL((qg_step_kernel_pair<1, false>), dim3(pblocks), dim3(QGK_WAVE), 0, stream, s->d_task, P, KWalkNone{}, KPoNone{});
     } else if (emap == QG_MAP_QUAD) {
         int qblocks = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
-        const bool one_wave = qblocks <= 1024;      // at most one wave per SIMD (256 CUs x 4): give each wave the whole register file
-        const bool wg4 = qblocks > 256;             // four-wave workgroups for grids of more than 256 waves
+        const bool one_wave = qblocks <= s->simds;  // at most one wave per SIMD (256 CUs x 4 on an MI355X): give each wave the whole register file
+        const bool wg4 = qblocks > s->simds / 4;    // four-wave workgroups for grids of more than one wave per compute unit
         dim3 g1(qblocks), b1(QGK_WAVE), g4((qblocks + 3) / 4), b4(QGK_WAVE * 4);
         if (s->baked) {
-            const int wpe = s->quad_wpe ? s->quad_wpe : (one_wave ? 1 : 2);
+            const int wpe = one_wave ? 1 : 2;
             if (wpe == 1 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
             else if (wpe == 1) hipLaunchKernelGGL((qg_step_kernel_quad<1, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
-            else if (wpe == 2 && !wg4) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
-            else if (wpe == 2) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
-            else if (wpe == 3) hipLaunchKernelGGL((qg_step_kernel_quad<3, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
-            else hipLaunchKernelGGL((qg_step_kernel_quad<4, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else if (!wg4) hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 1>), g1, b1, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
+            else hipLaunchKernelGGL((qg_step_kernel_quad<2, true, false, 4>), g4, b4, 0, stream, s->d_model, s->d_task, P, KWalkNone{}, KPoNone{});
         } else {
             // tables in LDS: the 256-register cap spills 888 B per lane and measured 2x slower at every grid size (363 vs 741 us
             // at 262 144 envs), so any other robot runs the one-wave-per-SIMD form throughout
@@ -687,7 +694,7 @@ extern "C" int qg_set_track_ctrl(qg_sim *s, int32_t on) {
 static int multi_step_usable(const qg_sim *s, const char *who) {
     if (effective_mapping(s) != QG_MAP_LINK)
         return fail(QG_ERR_ARG, "%s: needs the one-link-per-lane mapping (AUTO up to 4096 envs, lagged sensors)", who);
-    if (s->n > 1024 * QGK_LINK_ENVS) return fail(QG_ERR_ARG, "%s: at most %d envs (one wave per SIMD)", who, 1024 * QGK_LINK_ENVS);
+    if (s->n > s->simds * QGK_LINK_ENVS) return fail(QG_ERR_ARG, "%s: at most %d envs (one wave per SIMD)", who, s->simds * QGK_LINK_ENVS);
     if (s->walk_bound) return fail(QG_ERR_ARG, "%s: a walking task layer is bound to this handle", who);
     if (s->task.auto_reset && (s->task.reset_flags & QG_RESET_JOINT_JITTER))
         return fail(QG_ERR_ARG, "%s: hinge jitter at auto-reset is a launch of its own behind every step; not available in this form", who);

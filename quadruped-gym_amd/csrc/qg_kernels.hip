@@ -1012,7 +1012,7 @@ struct LegState {
 // share a SIMD (register cap 256), costs ~2 % when a wave has the register file to itself.
 // BAKED: the compiled-in robot, constants are literals and the lane works in its leg's quarter-turn frame.  Otherwise `C`
 // is the model table staged in LDS and every lane reads the constants of its own leg (k) from it -- any model numbers.
-template <bool BAKED, bool LOWREG, bool DIET = false>
+template <bool BAKED, bool LOWREG>
 DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
     const float h = C.h;
     const BaseCtx bc0 = base_prelude<true>(C, B);
@@ -1041,10 +1041,10 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         if constexpr (BAKED) {
             // this lane's leg, in the frame turned by its quarter turn: there it is leg 0
             Fr Ek = {v3(cm, sm, 0.f), v3(-sm, cm, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<float, true, true, LOWREG, DIET>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
+            leg_pass<float, true, true, LOWREG, false>(C, 0, Ek, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
         } else {
             Fr E0 = {v3(1.f, 0.f, 0.f), v3(0.f, 1.f, 0.f), v3(0.f, 0.f, 1.f)};
-            leg_pass<float, false, false, LOWREG, DIET>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
+            leg_pass<float, false, false, LOWREG, false>(C, k, E0, L.q, L.qd, L.act, bc, B.pw.z, h, Ic, fc, F, Hd, H01, H02, H12, bj, L.sc);
         }
         leg_eliminate(F, Hd, H01, H02, H12, bj, Y0, Y1, Y2, u, YFt, Fu);
         sub(Ic, YFt);                       // this leg's Schur complement
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
                                                                              const typename WalkArgT<WALK>::type WK,
                                                                              const typename PoArgT<PO>::type PK) {
     static_assert(WALK || !PO, "the observation pack rides on the walking task layer");
-    static_assert(!(PO && WPE > 2), "no fused observation pack in the register-capped development variants");
+    static_assert(WPE == 1 || WPE == 2, "register budget: one wave per SIMD (all 512 registers) or two");
     static_assert(!HELP || (WALK && WPE == 2), "helper waves: the walking forms at the two-waves-per-SIMD register budget");
     constexpr bool PO_COPY = PO && !HELP;          // HELP: the helper wave copies the history rows, nothing of it rides on the substep loop
     __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
@@ -1367,17 +1367,12 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     const bool lag = T->sensor_lag != 0;
     // Un-lagged sensors (task.sensor_lag = 0) take one extra forward pass whose state changes are discarded: the same loop body
     // runs once more with the state parked in LDS meanwhile -- one copy of the substep code and no extra live registers.
-    // DIET (register caps for three / four waves per SIMD, QG_QUAD_WPE=3|4): measured NOT to pay -- 196 vs 200 us at 262 144 envs,
-    // slower below (profiles/r02/wpe_ab.txt) -- kept selectable so the measurement can be repeated.  What it changes: one copy of
-    // the substep code also for un-lagged sensors (state parked in LDS during the extra pass), the quarter-turn products are
-    // recomputed per substep instead of hoisted, the epilogue's addresses / clipped action / substep counter are re-derived after
-    // the loop instead of carried through it (60 VGPRs of hoisted store addresses, tools/asm_liveness.py), compact per-link
-    // inertias in leg_pass.
-    constexpr bool DIET = WPE > 2;
+    // (Register caps for three / four waves per SIMD were built and measured in round 2 -- 197 / 255 us against 200 us at 262 144 envs,
+    // slower below: profiles/r02/wpe_ab.txt, docs/EXPERIMENTS.md -- and removed in round 4: WPE is 1 or 2.)
     int env_e = env, k_e = k;
     int nstep;
     float aclip[3];
-    if constexpr (!DIET) {
+    {
         // Code placement: a wave that is alone on its SIMD is sensitive to where the 14 KB loop body falls relative to the
         // instruction-fetch lines -- the same loop, shifted by one dword through an unrelated edit of the prologue, measured
         // 18.57 instead of 18.36 us per launch at 4096 envs (same-box A/B of eight paddings).  Pinning the loop to a 64-byte
@@ -1408,42 +1403,6 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
         nstep = nstep0 + fs;
 #pragma unroll
         for (int i = 0; i < 3; ++i) aclip[i] = aclip0[i];
-    } else {
-        __shared__ float park[25 * QGK_WAVE];
-        const int iters = lag ? fs : fs + 1;
-#pragma unroll 1
-        for (int s = 0; s < iters; ++s) {
-            const bool extra = s == fs;
-            if (extra) {
-                const float keep[25] = {B.pw.x, B.pw.y, B.pw.z, B.qw, B.qx, B.qy, B.qz, B.vw.x, B.vw.y, B.vw.z, B.wb.x, B.wb.y, B.wb.z,
-                                        L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2], L.act[0], L.act[1], L.act[2], L.u[0], L.u[1], L.u[2]};
-#pragma unroll
-                for (int j = 0; j < 25; ++j) park[j * QGK_WAVE + lane] = keep[j];
-            }
-            float cm_s = cm, sm_s = sm;
-            asm volatile("" : "+v"(cm_s), "+v"(sm_s));
-            substep_quad<BAKED, true, true>(C, cm_s, sm_s, B, L, lag ? (s == fs - 1) : extra, srow, k, zaxis_z);
-            if (extra) {
-                float keep[25];
-#pragma unroll
-                for (int j = 0; j < 25; ++j) keep[j] = park[j * QGK_WAVE + lane];
-                B.pw = v3(keep[0], keep[1], keep[2]); B.qw = keep[3]; B.qx = keep[4]; B.qy = keep[5]; B.qz = keep[6];
-                B.vw = v3(keep[7], keep[8], keep[9]); B.wb = v3(keep[10], keep[11], keep[12]);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    L.q[i] = keep[13 + i]; L.qd[i] = keep[16 + i]; L.act[i] = keep[19 + i]; L.u[i] = keep[22 + i];
-                    sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
-                }
-            }
-        }
-        asm volatile("" : "+v"(env_e), "+v"(k_e));
-        nstep = P.st.nstep[env_e] + fs;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float *asrc = P.actions;
-            if constexpr (WALK) asrc = WK.S.eff_actions;
-            aclip[i] = fminf(fmaxf(asrc[(size_t)env_e * 12 + 3 * k_e + i], -1.f), 1.f);     // quadruped.py:160
-        }
     }
     float ssq = 0.f;
 #pragma unroll

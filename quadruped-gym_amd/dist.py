@@ -17,6 +17,35 @@ def shard_range(total_envs: int, world: int, rank: int):
     return start, base + (1 if rank < rem else 0)
 
 
+def pci_to_ints(bus_id: str):
+    """'0000:05:00.0' -> (domain, bus, device, function); anything unparsable -> four -1."""
+    try:
+        dom, bus, rest = bus_id.strip().split(":")
+        dev, fn = rest.split(".")
+        return int(dom, 16), int(bus, 16), int(dev, 16), int(fn, 16)
+    except Exception:
+        return -1, -1, -1, -1
+
+
+def describe_group(device_ordinal: int, pci_bus_id: str, tensor_device, group=None):
+    """What the process group itself says about who is in it: every rank contributes (rank, device ordinal, PCI bus id) through ONE
+    all-gather over the group (RCCL for the ``nccl`` backend, so the answer comes over the same communicator the rollouts use) and
+    gets the same summary back -- ``world_size`` as the communicator reports it, the sorted members, how many distinct GPUs they
+    sit on.  ``bench.py`` prints it as ``config.rccl`` in every N > 1 line: "did RCCL see N ranks on N devices" is answerable from
+    the line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = torch.tensor([rank, int(device_ordinal), *pci_to_ints(pci_bus_id)], dtype=torch.int64, device=tensor_device)
+    everyone = torch.empty((world, 6), dtype=torch.int64, device=tensor_device)
+    dist.all_gather_into_tensor(everyone.view(-1), mine, group=group)
+    rows = sorted(tuple(int(x) for x in r) for r in everyone.cpu().tolist())
+    members = [{"rank": r[0], "device_ordinal": r[1], "pci_bus_id": ("%04x:%02x:%02x.%x" % r[2:6]) if r[2] >= 0 else None} for r in rows]
+    gpus = {m["pci_bus_id"] if m["pci_bus_id"] is not None else ("ordinal", m["device_ordinal"]) for m in members}
+    return {"backend": dist.get_backend(group), "world_size": world, "ranks_seen": len({m["rank"] for m in members}),
+            "distinct_gpus": len(gpus), "members": members}
+
+
 class PackedGatherer:
     """Per-step exchange of the packed rollout buffer, double-buffered so that the collective of step t overlaps the
     physics of step t+1 when the buffers live on a GPU.

@@ -116,6 +116,15 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(envs_per_gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["state_finite"] is True
     assert abs(d["value"] - 2 * envs_per_gpu / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job aggregate
     assert d["config"]["envs_per_gpu"] == envs_per_gpu and d["config"]["ctrl_tracking"] is True
+    # the line explains itself (round 4): who the communicator saw -- here two ranks that share GPU 0, which must SHOW -- and BASELINE
+    # config 4's shard timed in the same process (the driver only runs `bench.py --gpus N`, i.e. 4096 envs per GPU)
+    r = d["config"]["rccl"]
+    assert r["world_size"] == 2 and r["ranks_seen"] == 2 and r["distinct_gpus"] == 1 and r["backend"] == "gloo"
+    assert [m["rank"] for m in r["members"]] == [0, 1] and all(m["pci_bus_id"] for m in r["members"])
+    c4 = d["config4"]
+    assert c4["steps"] == 200 and c4["state_finite"] is True and "32768 envs/GPU x 2 GPU" in c4["workload"]
+    assert abs(c4["value"] - 2 * 32768 / (c4["ms_per_step"] * 1e-3)) < 1e-6 * c4["value"] and c4["mapping"] == "pair"
+    assert "pool of 16" in d["config"]["workload"]
 
 
 @pytest.mark.gpu

@@ -195,3 +195,36 @@ def test_graph_exchange_agreement_with_one_failing_rank_world2_gloo(fail_phase):
     want = {"capture": ["capture", "drop"], "warm": ["capture", "warm", "drop"], "timed": ["capture", "warm", "timed", "drop"]}[fail_phase]
     assert r0["calls"] == want and r1["calls"] == want          # nobody replays a graph its peer does not hold
     assert r0["captured"] == (fail_phase != "capture")
+
+
+def _describe_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from quadruped_gym_amd.dist import describe_group
+    # rank 1 reports the same GPU as rank 0 on purpose: the summary must show 2 ranks on ONE device
+    d = describe_group(device_ordinal=0, pci_bus_id="0000:05:00.0", tensor_device="cpu")
+    q.put((rank, d))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_describe_group_world2_gloo():
+    """``config.rccl`` of bench.py's N > 1 line: what the process group itself reports about its members (one all-gather over the
+    group), the same on every rank -- and it makes two ranks that share a GPU visible."""
+    from quadruped_gym_amd.dist import pci_to_ints
+    assert pci_to_ints("0000:05:00.0") == (0, 5, 0, 0) and pci_to_ints("0001:e3:00.0") == (1, 0xE3, 0, 0) and pci_to_ints("junk") == (-1,) * 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_describe_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert got[0] == got[1]
+    d = got[0]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_seen"] == 2 and d["distinct_gpus"] == 1
+    assert [m["rank"] for m in d["members"]] == [0, 1] and d["members"][1]["pci_bus_id"] == "0000:05:00.0"

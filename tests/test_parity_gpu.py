@@ -632,19 +632,6 @@ def test_unlagged_sensors_match_oracle(oracle, mapping):
     assert np.abs(obs0[:, 21:24] - obs1[:, 21:24]).max() > 1e-3
 
 
-@pytest.mark.parametrize("lag", [1, 0])
-@pytest.mark.parametrize("wpe", [2, 3, 4])
-def test_register_capped_quad_variants_match_oracle(oracle, wpe, lag):
-    """The one-leg-per-lane kernel exists in four register budgets (1..4 waves per SIMD; AUTO uses 1 up to 16 384 envs and 2
-    above, the 3 / 4-wave forms are kept for the occupancy measurement of profiles/r02/wpe_ab.txt and use a different loop
-    structure -- state parked in LDS for un-lagged sensors, compact per-link inertias).  QG_QUAD_WPE selects one at qg_create."""
-    os.environ["QG_QUAD_WPE"] = str(wpe)
-    try:
-        _one_step_against_oracle(oracle, 200, 500 + wpe, _abi.MAP_QUAD, sensor_lag=lag)
-    finally:
-        os.environ.pop("QG_QUAD_WPE", None)
-
-
 def test_host_step_is_ordered_after_a_graph_replay():
     """Replays of a hipGraph enqueue device-pointer steps the library never sees.  Capture 4 steps on a side stream, do a host step
     (which takes the device-wide wait and clears the in-flight flag), then replay the graph 40 times (~2 ms of queued kernels at this
