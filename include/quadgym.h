@@ -146,6 +146,10 @@ const char *qg_version(void);
  * committed profiles with it; bench.py flags a roofline entry that was measured on other sources (roofline.profile_stale). */
 const char *qg_build_id(void);
 const char *qg_last_error(void);
+/* The batch size at the top of the stair `n_envs` stands on: the step time is a staircase in the batch size (4096 / 16 384 / every
+ * further 32 768 envs on the 1024 SIMDs of an MI355X -- one wave per SIMD of the kernel AUTO picks), so this many envs cost no more
+ * per step than `n_envs` do.  4097 envs cost 55 % more per step than 4096.  device_id < 0: an MI355X. */
+int32_t qg_recommended_batch(int32_t n_envs, int32_t device_id);
 /* PCI bus id ("0000:05:00.0") of HIP device `device_id` into out[len >= 16] -- what bench.py's N > 1 line lists per rank, so that
  * "did RCCL see N ranks on N distinct GPUs" can be read off the line. */
 int qg_device_pci_bus_id(int32_t device_id, char *out, int32_t len);

@@ -159,6 +159,8 @@ def load_library():
     lib.qg_last_error.restype = C.c_char_p
     lib.qg_last_error.argtypes = []
     lib.qg_device_pci_bus_id.argtypes = [C.c_int32, C.c_char_p, C.c_int32]
+    lib.qg_recommended_batch.restype = C.c_int32
+    lib.qg_recommended_batch.argtypes = [C.c_int32, C.c_int32]
     lib.qg_default_model.argtypes = [C.POINTER(QgModel)]
     lib.qg_default_task.argtypes = [C.POINTER(QgTask)]
     lib.qg_time_limit_substeps.restype = C.c_int64
@@ -222,7 +224,8 @@ def load_library():
     lib.qg_resident_status.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("qg_version", "qg_build_id", "qg_last_error", "qg_time_limit_substeps", "qg_walk_state_bytes", "qg_po_state_bytes"):
+        if name not in ("qg_version", "qg_build_id", "qg_last_error", "qg_time_limit_substeps", "qg_walk_state_bytes", "qg_po_state_bytes",
+                        "qg_recommended_batch"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -230,7 +233,7 @@ def load_library():
 
 # every symbol include/quadgym.h declares
 EXPORTS = (
-    "qg_version", "qg_build_id", "qg_last_error", "qg_device_pci_bus_id", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
+    "qg_version", "qg_build_id", "qg_last_error", "qg_device_pci_bus_id", "qg_recommended_batch", "qg_default_model", "qg_default_task", "qg_time_limit_substeps",
     "qg_create", "qg_destroy", "qg_num_envs", "qg_obs_dim", "qg_reset", "qg_step", "qg_step_device",
     "qg_step_device_packed", "qg_get_state", "qg_step_mirror", "qg_set_state", "qg_time_step_kernel", "qg_set_track_ctrl", "qg_debug_phase_times", "qg_set_task", "qg_get_task",
     "qg_uses_baked_model", "qg_set_mapping", "qg_get_mapping",
@@ -253,6 +256,12 @@ def check(status: int, what: str):
     if status != 0:
         msg = load_library().qg_last_error().decode("utf-8", "replace")
         raise QuadGymError(f"{what} failed ({status}): {msg}")
+
+
+def recommended_batch(n_envs: int, device: int = -1) -> int:
+    """The batch size at the top of the step-time stair ``n_envs`` stands on (``qg_recommended_batch``): 4096, 16 384, then multiples
+    of 32 768 on an MI355X.  ``device=-1`` assumes an MI355X (no GPU needed)."""
+    return int(load_library().qg_recommended_batch(int(n_envs), int(device)))
 
 
 def default_model() -> QgModel:

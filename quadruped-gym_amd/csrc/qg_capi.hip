@@ -95,6 +95,21 @@ extern "C" const char *qg_version(void) { return "quadgym 0.1.0 (gfx950)"; }
 extern "C" const char *qg_build_id(void) { return QG_SOURCE_HASH; }
 extern "C" const char *qg_last_error(void) { return g_err; }
 
+// The step time is a staircase in the batch size (profiles/r03/map_sweep.txt, microseconds per env-step on an MI355X): flat at 11.8 up to
+// 4096 envs (one wave of the one-link-per-lane kernel per SIMD), 18.3-19.0 for 4097 .. 16 384 (one wave of the one-leg-per-lane kernel
+// per SIMD), 24.5-25.3 for 16 385 .. 32 768 (one wave of the two-legs-per-lane kernel per SIMD), then ~23 us per further 32 768 envs.
+// The top of a stair costs no more per step than its foot: this returns the top of the stair `n_envs` stands on.
+extern "C" int32_t qg_recommended_batch(int32_t n_envs, int32_t device_id) {
+    int simds = 1024;
+    hipDeviceProp_t prop;
+    if (device_id >= 0 && hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) simds = 4 * prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (n_envs < 1) n_envs = 1;
+    const int64_t link = (int64_t)simds * QGK_LINK_ENVS, quad = (int64_t)simds * QGK_QUAD_ENVS, pair = (int64_t)simds * QGK_PAIR_ENVS;
+    int64_t r = n_envs <= link ? link : (n_envs <= quad ? quad : ((n_envs + pair - 1) / pair) * pair);
+    return (int32_t)(r > INT32_MAX ? INT32_MAX : r);
+}
+
 extern "C" int qg_device_pci_bus_id(int32_t device_id, char *out, int32_t len) {
     if (!out || len < 16) return qg_fail(QG_ERR_ARG, "qg_device_pci_bus_id: need a buffer of at least 16 bytes");
     hipError_t e = hipDeviceGetPCIBusId(out, len, device_id);

@@ -96,3 +96,17 @@ def test_production_build_carries_no_phase_clock():
     out = (C.c_uint64 * 16)()
     assert lib.qg_debug_phase_times(out) == -1         # QG_ERR_ARG
     assert b"QG_PHASE_TIMES" in lib.qg_last_error()
+
+
+def test_recommended_batch_is_the_top_of_the_stair():
+    """The step time is a staircase in the batch size (one wave per SIMD of the kernel AUTO picks: 4096 / 16 384 / every further
+    32 768 envs on an MI355X); qg_recommended_batch rounds up to the top of the stair -- without a GPU it assumes the MI355X's 1024
+    SIMDs.  And no resident-mode entry point does anything without a handle."""
+    rb = _abi.recommended_batch
+    assert [rb(n) for n in (1, 4096, 4097, 16384, 16385, 32768, 32769, 65536, 65537)] == \
+        [4096, 4096, 16384, 16384, 32768, 32768, 65536, 65536, 98304]
+    lib = _abi.load_library()
+    assert lib.qg_resident_start(None, 1, 0, None, None) == -1 and lib.qg_resident_step_device(None, 1, None) == -1
+    assert lib.qg_step_device_seq(None, None, None, 1, None) == -1 and lib.qg_resident_stop(None) == -1
+    buf = C.create_string_buffer(8)
+    assert lib.qg_device_pci_bus_id(0, buf, 8) == -1   # too small a buffer is refused before any device call
