@@ -1,4 +1,4 @@
-"""frame_skip-20 accelerometer error of the link kernel against the oracle, by contact census (GPU box)."""
+"""(GPU box: python tools/accel_census.py)  frame_skip-20 accelerometer error of the link kernel against the oracle, by contact census (GPU box)."""
 import sys, numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tools")
 from oracle import oracle as O

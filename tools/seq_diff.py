@@ -1,3 +1,5 @@
+"""Bit-for-bit comparison of one sequence launch (qg_step_device_seq) against per-step launches: where and by how much they differ
+(GPU box: python tools/seq_diff.py)."""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from quadruped_gym_amd import _abi
