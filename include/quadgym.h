@@ -240,7 +240,8 @@ int qg_get_mapping(const qg_sim *sim);
  *
  * qg_step_device_seq: ONE launch runs `count` env-steps on actions[count][n_envs][12] and writes packed[count][n_envs][obs_dim + 2]
  * (device pointers, `stream` as for qg_step_device) -- open-loop sequences (action repeat, a planned sequence, K-step graphs).
- * Results are bit-identical to `count` calls of qg_step_device_packed.
+ * Results are bit-identical to `count` calls of qg_step_device_packed -- and where the one-launch form does not apply (more than
+ * 4096 envs, another mapping, hinge jitter at auto-reset) the call IS those `count` launches, so it means the same for every handle.
  *
  * The RESIDENT form (opt-in): qg_resident_start launches the step kernel once on the library's own stream; it stays on the GPU and
  * is handed each env-step through a mailbox in device memory -- `slots` action buffers [n_envs][12] and `slots` output buffers
@@ -249,9 +250,12 @@ int qg_get_mapping(const qg_sim *sim);
  * runnable and holds the stream until their rows are in memory -- a policy on the same stream stays in the loop (read the rows,
  * write the next slot's actions, ring); `count` > 1 lets the kernel run ahead through slots the caller filled beforehand.
  * Nothing in it waits without a deadline: a kernel that is not rung for `idle_timeout_us` (0 = 2000; 50 .. 100000) stores the
- * state and leaves; the next qg_resident_step_device (or qg_resident_ensure, for graph replays) launches it again.  A ring that
- * meets a retired kernel does NOT run its steps; the next resident call returns QG_ERR_LAUNCH and says how many (the state is that
- * of the last executed step).  Every entry point that needs the state in memory (reset, get / set_state, set_task, the per-launch
+ * state and leaves; the next qg_resident_step_device (or qg_resident_ensure, for graph replays) launches it again.  After HALF the
+ * time-out without a ring the kernel tells the host that it is about to leave (it still takes rings); the host then never rings it
+ * but retires it and launches again (tens of microseconds, synchronous) -- so a ring enqueued by qg_resident_step_device has half
+ * the time-out to reach the GPU before the door can shut on it.  A ring that does meet a retired kernel (a stream backlog longer
+ * than that, a replayed graph without qg_resident_ensure) does NOT run its steps; the next resident call returns QG_ERR_LAUNCH and
+ * says how many (the state is that of the last executed step).  Every entry point that needs the state in memory (reset, get / set_state, set_task, the per-launch
  * steps, destroy) first retires the kernel; qg_resident_stop retires it and frees the mailbox.
  * Measured: closed-loop rings cost MORE per env-step than a kernel launch; the form pays for run-ahead only. */
 int qg_step_device_seq(qg_sim *sim, const float *actions, float *packed, int32_t count, void *stream);

@@ -731,11 +731,19 @@ static dim3 multi_step_grid(const qg_sim *s) {
 
 extern "C" int qg_step_device_seq(qg_sim *s, const float *actions, float *packed, int32_t count, void *stream) {
     if (!s || !actions || !packed || count < 1) return fail(QG_ERR_ARG, "qg_step_device_seq: bad argument");
-    int rc = multi_step_usable(s, "qg_step_device_seq");
-    if (rc != QG_OK) return rc;
+    if (s->walk_bound) return fail(QG_ERR_ARG, "qg_step_device_seq: a walking task layer is bound to this handle");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
+    int rc;
     if (s->res.launched && (rc = resident_retire(s)) != QG_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (multi_step_usable(s, "qg_step_device_seq") != QG_OK) {
+        // another mapping (more than one wave per SIMD of the one-link-per-lane kernel), or hinge jitter behind every step: the same
+        // rows from `count` per-step launches -- the call means the same thing for every handle, the one-launch form is the fast path
+        const size_t arow = (size_t)s->n * QG_NU, prow = (size_t)s->n * (s->obs_dim + 2);
+        for (int32_t k = 0; k < count; k++)
+            if ((rc = launch_step(s, actions + k * arow, nullptr, nullptr, nullptr, nullptr, packed + k * prow, st)) != QG_OK) return rc;
+        return QG_OK;
+    }
     if (st != s->stream) {
         s->caller_inflight = 1;
         if (!s->captured_once) {
@@ -892,6 +900,12 @@ extern "C" int qg_resident_ensure(qg_sim *s) {
     if (!s->res.active) return fail(QG_ERR_ARG, "qg_resident_ensure: the resident step mode is off");
     HIP_TRY(hipSetDevice(s->device), QG_ERR_DEVICE);
     if (s->res.launched && s->res.hstat[0] == QG_RES_RUNNING) return QG_OK;
+    if (s->res.launched && s->res.hstat[0] == QG_RES_RETIRING) {
+        // no ring for half the time-out: the kernel may shut the door before a ring enqueued now reaches it.  Retire it here (it
+        // stores the state and leaves within microseconds) and launch it again: a fresh idle clock for what follows.
+        int rc = resident_retire(s);
+        if (rc != QG_OK) return rc;
+    }
     return resident_launch(s);        // stream-ordered behind the launch that has left (or is leaving)
 }
 

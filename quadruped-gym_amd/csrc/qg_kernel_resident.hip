@@ -28,6 +28,9 @@
 #define QG_RES_RUNNING 1ull         // hstat[0]
 #define QG_RES_EXIT_STOP 2ull       // retired on request (qg_resident_stop, or any entry point that needs the state in memory)
 #define QG_RES_EXIT_IDLE 3ull       // retired itself: no ring within idle_ticks
+#define QG_RES_RETIRING 4ull        // no ring for idle_ticks / 2: the kernel still takes rings, and leaves at idle_ticks if none comes.  The
+                                    // host does not ring a kernel in this state (it retires it and launches again): a ring it enqueues
+                                    // after seeing RUNNING therefore has idle_ticks / 2 to reach the GPU before the door can shut
 
 struct KResident {
     unsigned long long *door;       // device: env-steps rung so far | QG_DOOR_STOP
@@ -138,12 +141,26 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
             }
             if (seen <= kdone) {                                              // ... then wait for the next ring
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                bool go = false;
+                bool go = false, announced = false;
                 for (int polls = 0;; ++polls) {
                     const unsigned long long v = res_load_u64(R.door);
-                    if ((v & ~QG_DOOR_STOP) > kdone) { seen = v & ~QG_DOOR_STOP; go = true; exit_code = QG_RES_EXIT_STOP; break; }
+                    if ((v & ~QG_DOOR_STOP) > kdone) {
+                        seen = v & ~QG_DOOR_STOP; go = true; exit_code = QG_RES_EXIT_STOP;
+                        if (announced) __hip_atomic_store(R.hstat + 0, QG_RES_RUNNING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
                     if (v & QG_DOOR_STOP) break;
-                    if ((polls & 3) == 3 && __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)R.idle_ticks) {
+                    if ((polls & 3) != 3) {                                   // (the clock is a scalar memory read: every fourth poll)
+                        if (polls < 256) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(32);
+                        continue;
+                    }
+                    const unsigned long long idle = __builtin_amdgcn_s_memrealtime() - t0;
+                    if (!announced && idle > (unsigned long long)(R.idle_ticks >> 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+                        // half the time-out has passed: tell the host (it will not ring a kernel in this state), keep taking rings
+                        __hip_atomic_store(R.hstat + 0, QG_RES_RETIRING, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        announced = true;
+                    }
+                    if (idle > (unsigned long long)R.idle_ticks) {
                         // nobody rang: retire the kernel -- unless a ring gets in first (then the swap fails and the next poll sees it)
                         if (lane == 0) {
                             unsigned long long expect = kdone;

@@ -285,10 +285,17 @@ def test_resident_and_sequence_forms_refuse_what_they_do_not_cover():
     import torch
     from quadruped_gym_amd.sim import BatchedSim
     dev = torch.device("cuda:0")
-    big = BatchedSim(8192)                            # AUTO = one leg per lane
+    big, twin = BatchedSim(8192), BatchedSim(8192)   # AUTO = one leg per lane: the sequence call is then K per-step launches
+    acts = torch.rand((3, 8192, 12), device=dev) * 2 - 1
+    pa, pb = torch.zeros((3, 8192, 35), device=dev), torch.zeros((3, 8192, 35), device=dev)
+    big.step_device_seq(acts, pa)
+    for k in range(3):
+        twin.step_device_packed(acts[k], pb[k])
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb)
     with pytest.raises(_abi.QuadGymError, match="one-link-per-lane"):
-        big.step_device_seq(torch.zeros((2, 8192, 12), device=dev), torch.zeros((2, 8192, 35), device=dev))
-    big.close()
+        big.resident_start(torch.zeros((1, 8192, 12), device=dev), torch.zeros((1, 8192, 35), device=dev))
+    big.close(); twin.close()
     t = _abi.default_task()
     t.auto_reset = 1
     t.reset_flags = _abi.RESET_JOINT_JITTER
