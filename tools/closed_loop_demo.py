@@ -56,18 +56,21 @@ def run(mode):
     with torch.cuda.graph(graph, stream=side):
         for _ in range(G):
             one_step()
-    if mode == "resident":
-        sim.resident_ensure()
-    for _ in range(20):
-        graph.replay()
-    side.synchronize()
-    if mode == "resident":
-        sim.resident_ensure()
-    t0 = time.perf_counter()
-    for _ in range(steps // G):
-        graph.replay()
-    side.synchronize()
-    dt = time.perf_counter() - t0
+    # (a graph replays on the CURRENT stream; that stream -- not the device -- is what gets synchronised: a device-wide wait would also
+    # wait for the resident kernel, i.e. until it leaves for lack of rings)
+    with torch.cuda.stream(side):
+        if mode == "resident":
+            sim.resident_ensure()
+        for _ in range(20):
+            graph.replay()
+        side.synchronize()
+        if mode == "resident":
+            sim.resident_ensure()
+        t0 = time.perf_counter()
+        for _ in range(steps // G):
+            graph.replay()
+        side.synchronize()
+        dt = time.perf_counter() - t0
     k = (steps // G) * G
     extra = ""
     if mode == "resident":
