@@ -885,6 +885,7 @@ static int resident_check_reports(qg_sim *s, const char *who) {
     if (lost != s->res.lost_seen) {
         const uint64_t d = lost - s->res.lost_seen;
         s->res.lost_seen = lost;
+        s->res.rung -= (int64_t)d;        // those rings did not advance the door: the count (and the slot of the next env-step) follows the device
         return fail(QG_ERR_LAUNCH, "%s: %llu env-step(s) were rung after the resident kernel had retired and were NOT executed "
                     "(rings must follow one another within the idle time-out, or call qg_resident_ensure before a burst)", who, (unsigned long long)d);
     }

@@ -365,6 +365,20 @@ class QuadrupedVecEnv(_VecEnvBase):
         self._sim.step_device_packed(actions, packed, stream=stream)
         return packed
 
+    def step_sequence_tensor(self, actions, packed=None, stream=None):
+        """``K`` env-steps on actions known ahead: ``actions`` float32 CUDA ``[K, N, 12]`` -> the packed rows of every step
+        ``[K, N, obs_dim + 2]``.  ONE kernel launch with the state in registers between the steps where the handle allows it (up to
+        4096 envs: 9.2 instead of 11.8 us per env-step), ``K`` launches otherwise -- the rows are the same bits either way
+        (``qg_step_device_seq``).  Action repeat, evaluating a planned sequence, open-loop rollouts; device built-ins only."""
+        import torch
+        self._sync_task()
+        if self._host_rewards or self._host_terms:
+            raise RuntimeError("step_sequence_tensor runs the device built-ins only; Python reward / termination callables need step()")
+        if packed is None:
+            packed = torch.empty((int(actions.shape[0]), self.num_envs, self.obs_dim + 2), device=actions.device, dtype=torch.float32)
+        self._sim.step_device_seq(actions, packed, stream=stream)
+        return packed
+
     def sync_data(self):
         """Env-major host snapshot of the device state (``qpos [N,19]`` ...)."""
         d = self._snapshot

@@ -106,7 +106,7 @@ def test_sequence_launch_matches_golden_vectors():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("n,slots", [(4096, 1), (4096, 4), (1000, 2)])
+@pytest.mark.parametrize("n,slots", [(4096, 1), (4096, 4), (1000, 2), (3, 2)])
 def test_resident_closed_loop_is_bit_identical_to_per_step_launches(n, slots):
     """The resident kernel rung ONE env-step at a time (a policy in the loop: fresh actions written into the slot before every ring,
     the rows read back after it) against the per-launch kernel: every step's rows, the final state, the episode counters -- 120
@@ -234,6 +234,7 @@ def test_ring_that_meets_a_retired_kernel_runs_nothing_and_says_so():
     graph.replay(); _sync()          # ... and the replayed ring meets a retired door
     assert a.resident_status()["not_executed"] == 1
     assert torch.equal(mail_p, before)
+    assert a.resident_status()["rung"] == 1          # (rings of a replayed graph do not go through the API: one counted so far)
     with pytest.raises(_abi.QuadGymError, match="NOT executed"):
         a.resident_step(1)
     _same_state(a, b)                                 # one env-step has run, not two
@@ -313,3 +314,21 @@ def test_resident_and_sequence_forms_refuse_what_they_do_not_cover():
     sim.resident_stop()
     sim.set_mapping(_abi.MAP_QUAD)
     sim.close()
+
+
+def test_vec_env_sequence_steps_equal_single_steps():
+    """``QuadrupedVecEnv.step_sequence_tensor``: K env-steps in one call (one launch up to 4096 envs, K launches above) leave the rows of
+    K ``step_tensor`` calls, bit for bit, auto-resets included."""
+    import torch
+    from quadruped_gym_amd.envs.vec_env import QuadrupedVecEnv
+    dev = torch.device("cuda:0")
+    for n in (512, 6000):
+        kw = dict(reward_fns={"forward": 1.0, "control_cost": -0.1, "alive_bonus": 1.0}, termination_fns={"fall": 0.05}, max_time=0.1)
+        a, b = QuadrupedVecEnv(n, **kw), QuadrupedVecEnv(n, **kw)
+        a.reset(); b.reset()
+        acts = torch.rand((20, n, 12), device=dev) * 2 - 1
+        rows = a.step_sequence_tensor(acts)
+        ref = torch.stack([b.step_tensor(acts[k]).clone() for k in range(20)])
+        torch.cuda.synchronize()
+        assert torch.equal(rows, ref) and int(rows[:, :, -1].sum()) >= n
+        a.close(); b.close()
