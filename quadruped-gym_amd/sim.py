@@ -33,6 +33,14 @@ class BatchedSim:
         check(self._lib.qg_create(self.n, self.device, C.byref(self.model), C.byref(self.task), self.env_index_base,
                                   C.byref(h)), "qg_create")
         self._h = h
+        # the step time is a staircase in the batch size: just past a stair's top a batch is SLOWER in absolute
+        # terms than the top itself -- say so once, where it is worst (4097 .. ~6500 envs on an MI355X run below 4096 envs' env-steps/s)
+        top = _abi.recommended_batch(1, self.device)          # the first stair: one wave of the one-link-per-lane kernel per SIMD
+        if top < self.n <= int(1.6 * top):
+            import warnings
+            warnings.warn(f"{self.n} envs cost {_abi.recommended_batch(self.n, self.device)} envs' step time and run at fewer env-steps/s than "
+                          f"{top} envs do; use {top}, two handles of <= {top} on two streams, or >= {int(1.6 * top)} "
+                          f"(quadruped_gym_amd._abi.recommended_batch, INTEGRATION.md section 5)", stacklevel=2)
         self.obs_dim = self._lib.qg_obs_dim(self._h)
         self.baked = bool(self._lib.qg_uses_baked_model(self._h))
         self.limit_substeps = int(self._lib.qg_time_limit_substeps(self.model.timestep, self.task.max_time))
