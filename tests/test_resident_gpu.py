@@ -332,3 +332,43 @@ def test_vec_env_sequence_steps_equal_single_steps():
         torch.cuda.synchronize()
         assert torch.equal(rows, ref) and int(rows[:, :, -1].sum()) >= n
         a.close(); b.close()
+
+
+def test_sequence_and_resident_forms_with_other_model_numbers():
+    """Any other robot (here: one mass and one servo gain changed) runs the variants that stage the model tables in LDS
+    (``qg_step_kernel_link_multi<BAKED = false, ..>``): the sequence launch and closed-loop rings against per-step launches of the same
+    tables, bit for bit, through auto-resets."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    n, K = 1500, 16
+    model = _abi.default_model()
+    model.body_mass[3] *= 1.25
+    model.act_kp[1] = 85.0
+    task = _task()
+    sims = [BatchedSim(n, model=model, task=task) for _ in range(3)]
+    seq, ring, ref = sims
+    for s in sims:
+        assert not s.baked and s.mapping == _abi.MAP_LINK
+        s.reset(seed=2, flags=task.reset_flags)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(6)
+    mail_a = torch.zeros((1, n, 12), device=dev); mail_p = torch.zeros((1, n, 35), device=dev)
+    ring.resident_start(mail_a, mail_p)
+    finished = 0
+    for rnd in range(4):
+        acts = torch.rand((K, n, 12), generator=gen, device=dev) * 2 - 1
+        ps = torch.empty((K, n, 35), device=dev); pr = torch.empty((K, n, 35), device=dev); pg = torch.empty((K, n, 35), device=dev)
+        seq.step_device_seq(acts, ps)
+        for k in range(K):
+            ref.step_device_packed(acts[k], pr[k])
+            mail_a[0].copy_(acts[k])
+            ring.resident_step(1)
+            pg[k].copy_(mail_p[0])
+        _sync()
+        assert torch.equal(ps, pr) and torch.equal(pg, pr), rnd
+        finished += int(pr[:, :, -1].sum())
+    assert finished >= 2 * n and ring.resident_status()["not_executed"] == 0
+    _same_state(seq, ref); _same_state(ring, ref)
+    ring.resident_stop()
+    for s in sims:
+        s.close()
