@@ -575,6 +575,62 @@ def main():
 
     line = make_line(dt, kernel_ms, exchange_mode)
 
+    config4 = None
+    # ---- N > 1: BASELINE config 4's shard in the same process (the driver only ever runs `bench.py --gpus N`) -- BEFORE the hipGraph
+    # attempt below, so that a line printed by its watchdog carries it too ---------------------
+    # 262 144 envs over 8 GPUs = 32 768 per GPU, random yaw at every (re)set, per env-step ONE gather of the packed [32 768, obs + 2]
+    # f32 rows (4.59 MB per rank) to rank 0, double-buffered and overlapped exactly like the headline's (eager issue from the host).
+    k4 = args.config4_steps if args.config4_steps >= 0 else max(args.steps, 200)
+    if use_dist and native is None and walk is None and multi is None and k4 > 0 and gatherer is not None:
+        n4 = 32768
+        t4 = _abi.default_task()
+        t4.frame_skip, t4.obs_mode, t4.use_fall, t4.fall_height, t4.auto_reset = args.frame_skip, args.obs_mode, 1, 0.05, 1
+        t4.reset_flags = _abi.RESET_RANDOM_YAW
+        torch.cuda.set_stream(compute)
+        sim4 = BatchedSim(n4, device=local_rank, model=model, task=t4, env_index_base=rank * n4)
+        sim4.set_track_ctrl(not args.no_track_ctrl)
+        sim4.reset(seed=0, flags=t4.reset_flags)
+        pool4 = [torch.rand((n4, 12), generator=gen, device=dev) * 2 - 1 for _ in range(4)]
+        packed4 = [torch.empty((n4, row), device=dev) for _ in range(2)]
+        from quadruped_gym_amd.dist import PackedGatherer
+        g4 = PackedGatherer(n4, row, "cpu" if args.rehearse_shared_gpu else dev, dst=0, op=args.gather_op)
+        step4 = sim4.bind_step_packed(pool4, packed4, stream=compute)
+
+        def run4(count):
+            for k in range(count):
+                b = k & 1
+                g4.wait_buffer_free(compute)
+                step4(k & 3, b)
+                g4.submit(packed4[b].cpu() if args.rehearse_shared_gpu else packed4[b])
+                if len(g4.pending) > 64:
+                    del g4.pending[:-2]
+
+        def fence4():
+            g4.drain()
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        run4(max(args.warmup, 10))
+        fence4()
+        t0 = time.perf_counter()
+        run4(k4)
+        fence4()
+        dt4 = time.perf_counter() - t0
+        tm = torch.tensor([dt4], device="cpu" if args.rehearse_shared_gpu else dev, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt4 = float(tm.item())
+        k_ms4 = sim4.time_step_kernel(pool4[0], packed4[0], 100)
+        q4 = sim4.get_state()[0]
+        config4 = {"workload": f"BASELINE config 4: {n4} envs/GPU x {world} GPU = {n4 * world} envs, random yaw at every (re)set, "
+                                       f"frame_skip={args.frame_skip}, obs={od} f32, one {args.gather_op} of [{n4},{row}] f32 "
+                                       f"({n4 * row * 4 / 1e6:.2f} MB per rank) to rank 0 per env-step, actions from a pool of 4 buffers",
+                           "value": n4 * world * k4 / dt4, "unit": "env-steps/s", "steps": k4, "ms_per_step": dt4 / k4 * 1e3,
+                           "exchange": "eager (one torch.distributed collective per env-step, issued asynchronously, double-buffered)",
+                           "kernel_ms": k_ms4, "mapping": {_abi.MAP_QUAD: "quad", _abi.MAP_PAIR: "pair", _abi.MAP_LINK: "link",
+                                                           _abi.MAP_LANE: "lane"}[sim4.mapping],
+                           "state_finite": bool(np.isfinite(q4).all())}
+        sim4.close()
+        line["config4"] = config4
     # ---- multi-GPU, --exchange auto: the same K steps again as hipGraph replays, guarded by a watchdog -------------------------
     # The eager loop is bound by the host's cost of issuing one collective per step (29-39 us against a 14 us kernel); a graph of
     # 8 env-steps has no per-step host work.  (The same exchange from the library's C loop, --native-rccl, measured 32-36 us per step
@@ -655,60 +711,9 @@ def main():
                                                         f"hipGraph replay measured slower ({dt_g / args.steps * 1e6:.1f} us per step)"))
     if try_graph and G:
         line["config"]["exchange_us_per_step"] = tried
+    if config4 is not None:
+        line["config4"] = config4
 
-    # ---- N > 1: BASELINE config 4's shard in the same process (the driver only ever runs `bench.py --gpus N`) ---------------------
-    # 262 144 envs over 8 GPUs = 32 768 per GPU, random yaw at every (re)set, per env-step ONE gather of the packed [32 768, obs + 2]
-    # f32 rows (4.59 MB per rank) to rank 0, double-buffered and overlapped exactly like the headline's (eager issue from the host).
-    k4 = args.config4_steps if args.config4_steps >= 0 else max(args.steps, 200)
-    if use_dist and native is None and walk is None and multi is None and k4 > 0 and gatherer is not None:
-        n4 = 32768
-        t4 = _abi.default_task()
-        t4.frame_skip, t4.obs_mode, t4.use_fall, t4.fall_height, t4.auto_reset = args.frame_skip, args.obs_mode, 1, 0.05, 1
-        t4.reset_flags = _abi.RESET_RANDOM_YAW
-        torch.cuda.set_stream(compute)
-        sim4 = BatchedSim(n4, device=local_rank, model=model, task=t4, env_index_base=rank * n4)
-        sim4.set_track_ctrl(not args.no_track_ctrl)
-        sim4.reset(seed=0, flags=t4.reset_flags)
-        pool4 = [torch.rand((n4, 12), generator=gen, device=dev) * 2 - 1 for _ in range(4)]
-        packed4 = [torch.empty((n4, row), device=dev) for _ in range(2)]
-        from quadruped_gym_amd.dist import PackedGatherer
-        g4 = PackedGatherer(n4, row, "cpu" if args.rehearse_shared_gpu else dev, dst=0, op=args.gather_op)
-        step4 = sim4.bind_step_packed(pool4, packed4, stream=compute)
-
-        def run4(count):
-            for k in range(count):
-                b = k & 1
-                g4.wait_buffer_free(compute)
-                step4(k & 3, b)
-                g4.submit(packed4[b].cpu() if args.rehearse_shared_gpu else packed4[b])
-                if len(g4.pending) > 64:
-                    del g4.pending[:-2]
-
-        def fence4():
-            g4.drain()
-            torch.cuda.synchronize(dev)
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-        run4(max(args.warmup, 10))
-        fence4()
-        t0 = time.perf_counter()
-        run4(k4)
-        fence4()
-        dt4 = time.perf_counter() - t0
-        tm = torch.tensor([dt4], device="cpu" if args.rehearse_shared_gpu else dev, dtype=torch.float64)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        dt4 = float(tm.item())
-        k_ms4 = sim4.time_step_kernel(pool4[0], packed4[0], 100)
-        q4 = sim4.get_state()[0]
-        line["config4"] = {"workload": f"BASELINE config 4: {n4} envs/GPU x {world} GPU = {n4 * world} envs, random yaw at every (re)set, "
-                                       f"frame_skip={args.frame_skip}, obs={od} f32, one {args.gather_op} of [{n4},{row}] f32 "
-                                       f"({n4 * row * 4 / 1e6:.2f} MB per rank) to rank 0 per env-step, actions from a pool of 4 buffers",
-                           "value": n4 * world * k4 / dt4, "unit": "env-steps/s", "steps": k4, "ms_per_step": dt4 / k4 * 1e3,
-                           "exchange": "eager (one torch.distributed collective per env-step, issued asynchronously, double-buffered)",
-                           "kernel_ms": k_ms4, "mapping": {_abi.MAP_QUAD: "quad", _abi.MAP_PAIR: "pair", _abi.MAP_LINK: "link",
-                                                           _abi.MAP_LANE: "lane"}[sim4.mapping],
-                           "state_finite": bool(np.isfinite(q4).all())}
-        sim4.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.frame_skip, args.cpu_seconds)
