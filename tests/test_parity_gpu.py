@@ -791,3 +791,76 @@ def test_standing_height_at_the_joint_centre_command_4096_envs(oracle):
     assert (qpos == qpos[0]).all()                                                # identical envs, identical bits
     assert (qpos[:, 2] - 0.13).min() > 0.012
     sim.close()
+
+
+@pytest.mark.parametrize("trial", range(10))
+def test_random_task_and_model_variants_match_oracle(oracle, trial):
+    """Ten seeded variants the other tests do not visit: a perturbed robot (masses, inertias, servo gains, damping, contact and limit
+    parameters -- the kernel variants that read the model tables from LDS / scalar loads), frame_skip 1 ... 8, either observation pack,
+    random reward weights and fall height, every mapping that serves the variant.  One env-step from seeded rollout states against the
+    oracle run on the SAME perturbed numbers, within the frame_skip-4 bounds scaled by frame_skip / 4 (the error compounds per substep)."""
+    import sys
+    from quadruped_gym_amd.sim import BatchedSim
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from make_golden import sample_states
+    rng = np.random.default_rng(1000 + trial)
+    fs = int(rng.choice([1, 2, 3, 5, 8]))
+    obs_mode = int(rng.integers(0, 2))
+    perturb = trial % 3 != 0                              # every third trial keeps the compiled-in robot (literal-constant kernels)
+
+    def shape(model, task):
+        if perturb:
+            for b in range(13):
+                model.body_mass[b] *= float(r_model[0][b])
+                for i in range(6):
+                    model.body_inertia[b][i] *= float(r_model[0][b])
+            for j in range(12):
+                model.act_kp[j] *= float(r_model[1][j]); model.act_kv[j] *= float(r_model[2][j]); model.jnt_damping[j] *= float(r_model[3][j])
+            model.contact_stiffness *= float(r_model[4][0]); model.contact_damping *= float(r_model[4][1])
+            model.limit_stiffness *= float(r_model[4][2]); model.free_damping *= float(r_model[4][3])
+        task.frame_skip, task.obs_mode = fs, obs_mode
+        task.use_fall, task.fall_height = 1, float(r_task[0])
+        task.w_forward, task.w_ctrl, task.alive_bonus = float(r_task[1]), float(r_task[2]), float(r_task[3])
+        return model, task
+    # trials 1, 4, 7: the legs stay quarter-turn copies of one another (the same factor for the four copies of a link / hinge)
+    per_link = rng.uniform(0.8, 1.25, 4)                  # FRAME, fema, shin, foot
+    body_f = np.array([per_link[0]] + [per_link[1 + (b % 3)] for b in range(12)])
+    r_model = [body_f, np.tile(rng.uniform(0.8, 1.2, 3), 4), np.tile(rng.uniform(0.8, 1.2, 3), 4), np.tile(rng.uniform(0.7, 1.3, 3), 4),
+               rng.uniform(0.8, 1.2, 4)]
+    if trial % 3 == 2:                                    # ... and a robot whose four legs DIFFER from one another (a payload on one side,
+        r_model[0] = rng.uniform(0.8, 1.25, 13)           # an ageing servo): nothing in the table-driven kernels assumes the symmetry
+        r_model[1], r_model[2], r_model[3] = rng.uniform(0.8, 1.2, 12), rng.uniform(0.8, 1.2, 12), rng.uniform(0.7, 1.3, 12)
+    r_task = [rng.uniform(0.03, 0.08), rng.uniform(-2, 2), rng.uniform(-0.5, 0.0), rng.uniform(0, 2)]
+    model, otask = shape(oracle.default_model(), oracle.default_task())
+    n = 96
+    qpos, qvel, act, nstep = sample_states(model, otask, n, seed=500 + trial)
+    actions = rng.uniform(-1.3, 1.3, (n, 12)).astype(np.float32)
+    b = oracle.Batch(model, otask, n)
+    b.set_state(qpos.astype(np.float64), qvel.astype(np.float64), act.astype(np.float64), None, nstep)
+    obs_o, rew_o, done_o, comps_o = b.step(actions.astype(np.float64))
+    q_o, v_o, a_o, c_o, n_o = b.get_state()
+    gmodel, gtask = shape(_abi.default_model(), _abi.default_task())
+    scale = max(1.0, fs / 4.0)
+    t = {k: (v[0] * scale, v[1] * scale) for k, v in TOL["A"].items()}
+    od = 21 if obs_mode else 33
+    mask = np.ones(od, bool)
+    mask[12:15] = False
+    for name in (["lane", "quad", "link"] + ([] if perturb else ["pair"])):
+        sim = BatchedSim(n, model=gmodel, task=gtask)
+        assert sim.baked == (not perturb)
+        sim.set_mapping(MAPPINGS[name])
+        sim.set_state(qpos, qvel, act, None, nstep)
+        obs, rew, done, comps = sim.step(actions, want_components=True)
+        q1, v1, a1, c1, n1 = sim.get_state()
+        sim.close()
+        what = f"trial {trial} ({'perturbed' if perturb else 'built-in'} robot, frame_skip {fs}, obs {od}) {name}: "
+        close(q1, q_o, t["qpos"], what + "qpos")
+        close(v1, v_o, t["qvel"], what + "qvel")
+        close(a1, a_o, t["act"], what + "act")
+        assert np.array_equal(n1, n_o) and np.array_equal(c1, c_o.astype(np.float32))
+        close(obs[:, mask], obs_o[:, mask], t["obs"], what + "obs")
+        close(obs[:, 12:15], obs_o[:, 12:15], t["accel"], what + "accelerometer")
+        close(rew, rew_o, t["reward"], what + "reward")
+        close(comps, comps_o, t["reward"], what + "reward components")
+        sure = np.abs(q_o[:, 2] - gtask.fall_height) > 1e-4
+        assert np.array_equal(np.asarray(done)[sure], done_o[sure])
