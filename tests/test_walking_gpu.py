@@ -541,3 +541,57 @@ def test_helper_waves_equal_the_one_role_kernel(po, n, steps, monkeypatch):
     assert resets > 0
     for e in envs:
         e.close()
+
+
+@pytest.mark.parametrize("trial,mapping", [(0, "auto"), (1, "quad"), (2, "pair"), (3, "auto")])
+def test_walking_rewards_with_other_task_parameters_match_oracle(trial, mapping):
+    """The walking task layer with every constant of walking_quad.py moved (reward weights :362-383, control-cost and estimator
+    smoothing :54-59,:254, body height :369, joint centres :36-39, amplitude / frequency targets :272-285, estimator window through
+    min_freq) and frame_skip 10 (the training setting, train_quadruped.py:18) or 5: the kernels take all of them as data
+    (qg_walk_params), and the oracle given the same numbers must agree on all eleven components over a window wrap."""
+    from quadruped_gym_amd.envs.walking import WalkingQuadrupedVecEnv, default_walk_params
+    rng = np.random.default_rng(40 + trial)
+    fs = 10 if trial % 2 == 0 else 5
+    n, dt, settle = 50, 0.002 * fs, 0.04
+    p = default_walk_params()
+    po = W.default_params()
+    po["w"] = np.array(po["w"]) * rng.uniform(0.5, 1.5, 10)
+    po["w_diff_ideal"] = float(-20.0 * rng.uniform(0.5, 1.5))
+    po["control_cost_alpha"] = float(rng.uniform(0.5, 0.95)); po["ema_alpha"] = float(rng.uniform(0.6, 0.95))
+    po["min_freq"] = float(rng.choice([1.0, 2.0, 0.8])); po["body_height"] = float(rng.uniform(0.1, 0.15))
+    po["joint_centers"] = np.tile(rng.uniform(-0.4, 0.3, 3), 4)
+    po["amp_target"] = np.tile(rng.uniform(0.0, 1.5, 3), 4); po["freq_target"] = np.tile(rng.uniform(0.0, 2.0, 3), 4)
+    for i in range(10):
+        p.w[i] = float(po["w"][i])
+    p.w_diff_ideal, p.control_cost_alpha, p.ema_alpha = po["w_diff_ideal"], po["control_cost_alpha"], po["ema_alpha"]
+    p.min_freq, p.body_height = po["min_freq"], po["body_height"]
+    for j in range(12):
+        p.joint_centers[j], p.amp_target[j], p.freq_target[j] = float(po["joint_centers"][j]), float(po["amp_target"][j]), float(po["freq_target"][j])
+    env = WalkingQuadrupedVecEnv(n, settling_time=settle, frame_skip=fs, max_time=1000.0, walk_params=p)
+    env._sim.set_mapping({"auto": _abi.MAP_AUTO, "quad": _abi.MAP_QUAD, "pair": _abi.MAP_PAIR}[mapping])
+    o = W.WalkingOracle(n, dt, settling_time=settle, params=po)
+    sp, al, th = rng.uniform(0.1, 0.5, n), rng.uniform(-np.pi, np.pi, n), rng.uniform(-np.pi, np.pi, n)
+    for i in range(n):
+        o.controls.set_orientation(i, th[i])
+        o.controls.set_velocity_speed_alpha(i, sp[i], al[i])
+    env.set_commands(o.controls.velocity[:, :2], o.controls.heading[:, :2])
+    env.reset(); o.reset()
+    data_ctrl = np.tile(po["joint_centers"], (n, 1)) * 0 + np.tile([0, 0, -0.5] * 4, (n, 1))        # quadruped.py:124, whatever the centres
+    ph = rng.uniform(0, 2 * np.pi, (n, 12)); fr = rng.uniform(0.5, 4.0, (n, 12)); am = rng.uniform(0.1, 1.2, (n, 12))
+    t = 0.0
+    for k in range(o.est.W + 25):
+        a = (am * np.sin(2 * np.pi * fr * k * dt + ph) + 0.05 * rng.normal(size=(n, 12))).astype(np.float32)
+        obs, rew, dones, infos = env.step(a)
+        assert not dones.any()
+        act = o.pre_step(np.full(n, t), data_ctrl, a.astype(np.float64))
+        ctrl = np.clip(act, -1, 1)
+        tot, comps, flip = o.post_step(obs.astype(np.float64), ctrl)
+        got = env.last_components.astype(np.float64)
+        assert np.allclose(got[:, :10], comps[:, :10], rtol=3e-4, atol=3e-4, equal_nan=True), (k, np.nanmax(np.abs(got[:, :10] - comps[:, :10])))
+        assert np.allclose(got[:, 10], comps[:, 10], rtol=1e-3, atol=3e-2 / dt * 1e-3 + 1e-3), k
+        assert np.allclose(rew, got.sum(1), rtol=1e-5, atol=2e-4, equal_nan=True)
+        data_ctrl = ctrl
+        t += 0.002 * fs
+    f, amp, ideal = env.estimates()
+    assert np.allclose(f, o.f_est, rtol=1e-4, atol=1e-4) and np.allclose(amp, o.a_est, rtol=1e-4, atol=1e-5)
+    env.close()
