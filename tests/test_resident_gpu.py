@@ -106,7 +106,7 @@ def test_sequence_launch_matches_golden_vectors():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("n,slots", [(4096, 1), (4096, 4), (1000, 2), (3, 2)])
+@pytest.mark.parametrize("n,slots", [(4096, 1), (4096, 4), (1000, 2), (3, 2), (1, 1)])
 def test_resident_closed_loop_is_bit_identical_to_per_step_launches(n, slots):
     """The resident kernel rung ONE env-step at a time (a policy in the loop: fresh actions written into the slot before every ring,
     the rows read back after it) against the per-launch kernel: every step's rows, the final state, the episode counters -- 120

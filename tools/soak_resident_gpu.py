@@ -42,6 +42,7 @@ rung = 0                        # env-steps rung since resident_start: the next 
 ops = {k: 0 for k in ("ring1", "ringm", "idle", "state", "reset", "launch", "seq", "task")}
 steps = relaunch = 0
 t_end = time.perf_counter() + seconds
+t_report = time.perf_counter() + 30.0
 it = 0
 while time.perf_counter() < t_end:
     it += 1
@@ -89,6 +90,9 @@ while time.perf_counter() < t_end:
     elif op == "task":
         t = task(max_time=float(rng.choice([0.2, 0.3, 0.5])), fs=int(rng.choice([2, 4, 4, 6])))
         a.set_task(t); b.set_task(t)
+    if time.perf_counter() > t_report:
+        t_report += 30.0
+        print(f"  ... {it} operations, {steps} env-steps, {relaunch} launches after leaving, rings not executed {a.resident_status()['not_executed']}", flush=True)
     if it % 300 == 0:
         for x, y in zip(a.get_state(), b.get_state()):
             assert np.array_equal(x, y), (it, "periodic state")
