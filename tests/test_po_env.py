@@ -294,3 +294,35 @@ def test_po_atan2_form_is_accurate_to_3e7():
     s = np.sqrt(np.maximum((f(1) - v) * (f(1) + v), f(0))).astype(f)
     err = np.abs(po_atan2(v, s).astype(np.float64) - np.arcsin(v.astype(np.float64)))
     assert err.max() < 5e-7, err.max()
+
+
+@pytest.mark.gpu
+def test_restore_is_all_or_nothing():
+    """``restore()`` checks every part of a snapshot against the env BEFORE it writes anything (round-3 advisor finding: the physics and
+    the reset streams used to be overwritten before a mismatching task-layer blob was refused): a walking-only snapshot restored into a
+    PO env, and a snapshot from another obs_window, are refused and leave the env exactly where it was."""
+    from quadruped_gym_amd.envs.walking import POWalkingQuadrupedVecEnv, WalkingQuadrupedVecEnv
+    n = 33
+    kw = dict(frame_skip=4, max_time=0.2, random_init=True, random_controls=True, device_commands=True, seed=3)
+    po = POWalkingQuadrupedVecEnv(n, obs_window=4, **kw)
+    walk = WalkingQuadrupedVecEnv(n, **kw)
+    other = POWalkingQuadrupedVecEnv(n, obs_window=6, **kw)
+    rng = np.random.default_rng(0)
+    for e in (po, walk, other):
+        e.reset()
+    for _ in range(12):
+        a = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+        for e in (po, walk, other):
+            e.step(a)
+    before = po.snapshot()
+    for bad in (walk.snapshot(), other.snapshot()):
+        with pytest.raises(ValueError):
+            po.restore(bad)
+        after = po.snapshot()
+        for key in ("walk", "po", "velocity", "heading"):
+            assert np.array_equal(before[key], after[key]), key
+        for key in before["sim"]:
+            assert np.array_equal(before["sim"][key], after["sim"][key]), key
+    po.restore(before)                                   # and a matching one still goes in
+    for e in (po, walk, other):
+        e.close()
