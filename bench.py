@@ -534,7 +534,9 @@ def main():
             "state_finite": healthy,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "profile_stale": stale, "profile_build_id": prof_id, "build_id": build_id,
-                         "kernel": MAP_KERNEL[sim.mapping] if multi is None else "qg_step_kernel_link_multi",
+                         "kernel": MAP_KERNEL[sim.mapping] if multi is None else
+                                   {_abi.MAP_LINK: "qg_step_kernel_link_multi", _abi.MAP_PAIR: "qg_step_kernel_pair_multi", _abi.MAP_QUAD: "qg_step_kernel_quad_multi"}.get(
+                                       sim.mapping, MAP_KERNEL[sim.mapping] + " (per-step launches: no one-launch form for this mapping)"),
                          "fence": "timed-stream synchronize (rings complete when their rows are out)" if args.resident else "device synchronize",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_step * n,
                          "algorithmic_bytes_per_env_step": bytes_step,

@@ -234,14 +234,16 @@ int qg_uses_baked_model(const qg_sim *sim);
 int qg_set_mapping(qg_sim *sim, int32_t mapping);
 int qg_get_mapping(const qg_sim *sim);
 
-/* ---- many env-steps per launch (round 4; one-link-per-lane mapping, <= 4096 envs, packed rows, no task layer) ----------------
+/* ---- many env-steps per launch (round 4; packed rows, no task layer) -----------------------------------------------------------
  * The reference keeps an env's state in MjData across steps (quadruped.py:163-165: the hot loop re-reads nothing); the per-launch
  * step kernel re-loads and stores it around every env-step.  Two forms keep it in registers instead:
  *
  * qg_step_device_seq: ONE launch runs `count` env-steps on actions[count][n_envs][12] and writes packed[count][n_envs][obs_dim + 2]
  * (device pointers, `stream` as for qg_step_device) -- open-loop sequences (action repeat, a planned sequence, K-step graphs).
- * Results are bit-identical to `count` calls of qg_step_device_packed -- and where the one-launch form does not apply (more than
- * 4096 envs, another mapping, hinge jitter at auto-reset) the call IS those `count` launches, so it means the same for every handle.
+ * Results are bit-identical to `count` calls of qg_step_device_packed.  Every mapping AUTO picks has its one-launch form (one link
+ * per lane up to 4096 envs, one leg per lane, two legs per lane); where none applies (the one-env-per-lane mapping, un-lagged
+ * sensors, hinge jitter at auto-reset, explicit mapping requests on small grids) the call IS those `count` launches, so it means
+ * the same for every handle.  The resident form below exists for the one-link-per-lane mapping (<= 4096 envs) only.
  *
  * The RESIDENT form (opt-in): qg_resident_start launches the step kernel once on the library's own stream; it stays on the GPU and
  * is handed each env-step through a mailbox in device memory -- `slots` action buffers [n_envs][12] and `slots` output buffers

@@ -736,6 +736,55 @@ extern "C" int qg_step_device_seq(qg_sim *s, const float *actions, float *packed
     int rc;
     if (s->res.launched && (rc = resident_retire(s)) != QG_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    const bool seq_pair = effective_mapping(s) == QG_MAP_PAIR && s->baked && s->task.sensor_lag &&
+                          !(s->task.auto_reset && (s->task.reset_flags & QG_RESET_JOINT_JITTER));
+    if (seq_pair) {                   // the two-legs-per-lane mapping (16 385 .. 32 768 envs, >= 57 344): its own one-launch form
+        if (st != s->stream) {
+            s->caller_inflight = 1;
+            if (!s->captured_once) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) s->captured_once = 1;
+            }
+        }
+        KResident R = {};
+        R.actions = actions;
+        R.packed = packed;
+        R.count = count;
+        R.slots = 1;
+        const KStepArgs P = multi_step_args(s);
+        const int pblocks = (s->n + QGK_PAIR_ENVS - 1) / QGK_PAIR_ENVS;
+        if (pblocks > s->simds / 4) hipLaunchKernelGGL((qg_step_kernel_pair_multi<4>), dim3((pblocks + 3) / 4), dim3(QGK_WAVE * 4), 0, st, s->d_task, P, R);
+        else hipLaunchKernelGGL((qg_step_kernel_pair_multi<1>), dim3(pblocks), dim3(QGK_WAVE), 0, st, s->d_task, P, R);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_step_kernel_pair_multi launch: %s", hipGetErrorString(e));
+        return QG_OK;
+    }
+    const int qblocks_seq = (s->n + QGK_QUAD_ENVS - 1) / QGK_QUAD_ENVS;
+    const bool seq_quad = effective_mapping(s) == QG_MAP_QUAD && s->task.sensor_lag && qblocks_seq > s->simds / 4 &&
+                          !(s->task.auto_reset && (s->task.reset_flags & QG_RESET_JOINT_JITTER));
+    if (seq_quad) {                   // the one-leg-per-lane mapping on the grids AUTO gives it (four-wave workgroups): its own one-launch form
+        if (st != s->stream) {
+            s->caller_inflight = 1;
+            if (!s->captured_once) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (st && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) s->captured_once = 1;
+            }
+        }
+        KResident R = {};
+        R.actions = actions;
+        R.packed = packed;
+        R.count = count;
+        R.slots = 1;
+        const KStepArgs P = multi_step_args(s);
+        const dim3 g4((qblocks_seq + 3) / 4), b4(QGK_WAVE * 4);
+        const bool one_wave = qblocks_seq <= s->simds;          // as launch_step: the whole register file while the grid is one wave per SIMD
+        if (!s->baked) hipLaunchKernelGGL((qg_step_kernel_quad_multi<1, false>), g4, b4, 0, st, s->d_model, s->d_task, P, R);   // (tables in LDS: always the one-wave form)
+        else if (one_wave) hipLaunchKernelGGL((qg_step_kernel_quad_multi<1, true>), g4, b4, 0, st, s->d_model, s->d_task, P, R);
+        else hipLaunchKernelGGL((qg_step_kernel_quad_multi<2, true>), g4, b4, 0, st, s->d_model, s->d_task, P, R);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(QG_ERR_LAUNCH, "qg_step_kernel_quad_multi launch: %s", hipGetErrorString(e));
+        return QG_OK;
+    }
     if (multi_step_usable(s, "qg_step_device_seq") != QG_OK) {
         // another mapping (more than one wave per SIMD of the one-link-per-lane kernel), or hinge jitter behind every step: the same
         // rows from `count` per-step launches -- the call means the same thing for every handle, the one-launch form is the fast path

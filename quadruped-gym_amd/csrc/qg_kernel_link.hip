@@ -104,19 +104,6 @@ DEV float leg_prefix(float x) {
 }
 DEV V3 leg_prefix(V3 a) { return v3(leg_prefix(a.x), leg_prefix(a.y), leg_prefix(a.z)); }
 
-// The quaternion scaled to unit length at the head of an env-step.  The sum of squares is written out as explicit multiply-adds: left
-// to the compiler's contraction, w*w + x*x may become fma(w, w, x*x) in one kernel and fma(x, x, w*w) in another (it did: the
-// per-launch kernel and the many-steps-per-launch kernel of qg_kernel_resident.hip differed by one ulp in a few envs per step),
-// and those two kernels must leave the same bits.
-DEV void quat_unit(BaseState &B) {
-    float d = B.qx * B.qx;
-    d = fmaf(B.qw, B.qw, d);
-    d = fmaf(B.qy, B.qy, d);
-    d = fmaf(B.qz, B.qz, d);
-    const float qn = __builtin_amdgcn_rsqf(d);
-    B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
-}
-
 // what link r needs as per-lane data (registers)
 struct LinkRegs {
     float mass, ipos[3], inertia[6], cp[QGK_CP_LINK][3];
@@ -618,7 +605,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES * (HELP ? 2 : 1), 1) void
     float c_fwd = Tk.w_forward * B.vw.x;
     float c_ctl = Tk.w_ctrl * ssq;
     float c_alive = Tk.alive_bonus;
-    float reward = c_fwd + c_ctl + c_alive;
+    float reward = reward_total(c_fwd, c_ctl, c_alive);
     bool done = nstep >= Tk.limit_substeps;
     if (Tk.use_fall) done = done || (B.pw.z < Tk.fall_height);
     {

@@ -20,8 +20,9 @@
 //     exits; the host sees `state = exited` in page-locked memory and launches again before it rings next;
 //   * waves never wait for each other: no workgroup barrier in the loop (arrival is per wave), so no exit order can deadlock;
 //   * the ring kernel's wait for the arrivals gives up after a period without progress and reports it.
-// Out of scope of these forms (the launcher refuses): the walking / observation-pack layers, un-lagged sensors, hinge jitter at
-// auto-reset (a launch of its own behind every per-launch step), separate obs / reward / done outputs (packed rows only).
+// Out of scope of these forms (the launcher refuses, or falls back to per-step launches): the walking / observation-pack layers,
+// un-lagged sensors, hinge jitter at auto-reset (a launch of its own behind every per-launch step), separate obs / reward / done
+// outputs (packed rows only).  The sequence form also exists for the two-legs-per-lane and the one-leg-per-lane kernels (end of file).
 
 #define QG_DOOR_STOP (1ull << 63)
 #define QG_RES_SHARDS 32            // arrival counters, one 128-byte line each; wave w of the grid arrives at shard w % 32
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(QGK_WAVE * QGK_LINK_WAVES, 1) void qg_step_kernel_l
         const float c_fwd = Tk.w_forward * B.vw.x;
         const float c_ctl = Tk.w_ctrl * ssq;
         const float c_alive = Tk.alive_bonus;
-        const float reward = c_fwd + c_ctl + c_alive;
+        const float reward = reward_total(c_fwd, c_ctl, c_alive);
         bool done = nstep >= Tk.limit_substeps;
         if (Tk.use_fall) done = done || (B.pw.z < Tk.fall_height);
         {
@@ -363,5 +364,337 @@ __global__ void qg_resident_ctl_kernel(unsigned long long *door, int op) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (op == 0) (void)__hip_atomic_fetch_or(door, QG_DOOR_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else (void)__hip_atomic_fetch_and(door, ~QG_DOOR_STOP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- the sequence form for the two-legs-per-lane kernel (16 385 .. 32 768 envs and >= 57 344: BASELINE configs 3 and 4's sizes) ----------
+// qg_step_kernel_pair with an outer loop over env-steps, exactly as qg_step_kernel_link_multi<.., DOOR = false> is to qg_step_kernel_link:
+// state loaded once and stored once, per env-step what a fresh launch does with the state it loads, bit-identical results.  Compiled-in
+// robot, lagged sensors, packed rows (the launcher falls back to per-step launches otherwise).
+template <int WAVES>
+__global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair_multi(const KTask *__restrict__ T, KStepArgs P, KResident R) {
+    __shared__ float tile_all[WAVES][QGK_PAIR_ENVS * 35];
+    const KModel &C = QG_BAKED_MODEL;
+    const int lane = threadIdx.x & (QGK_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    float *tile = tile_all[wave];
+    const int half = lane & 1;
+    const int el = lane >> 1;
+    const int env0 = (blockIdx.x * WAVES + wave) * QGK_PAIR_ENVS;
+    const int n = P.n;
+    const bool live = env0 + el < n;
+    int env = live ? env0 + el : n - 1;
+    f2 cm, sm;
+    cm.x = half ? -1.f : 1.f; cm.y = 0.f;
+    sm.x = 0.f; sm.y = half ? -1.f : 1.f;
+    struct { int32_t frame_skip, limit_substeps, use_fall, use_flip, obs_mode, auto_reset; uint32_t reset_flags; float fall_height, w_forward, w_ctrl, alive_bonus;
+             const float *default_ctrl; } Tk = {T->frame_skip, T->limit_substeps, T->use_fall, T->use_flip, T->obs_mode, T->auto_reset, T->reset_flags,
+                                               T->fall_height, T->w_forward, T->w_ctrl, T->alive_bonus, T->default_ctrl};
+
+    BaseState B;
+    B.pw = v3<float>(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
+    B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
+    B.vw = v3<float>(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
+    B.wb = v3<float>(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    int nstep = P.st.nstep[env];
+    int episode = P.st.episode[env];
+    LegPair L;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = 3 * (2 * half + c) + i;
+            const float qq = P.st.qpos[(7 + j) * n + env], qv = P.st.qvel[(6 + j) * n + env], aa = P.st.act[j * n + env];
+            if (c == 0) { L.q[i].x = qq; L.qd[i].x = qv; L.act[i].x = aa; L.u[i].x = 0.f; }
+            else { L.q[i].y = qq; L.qd[i].y = qv; L.act[i].y = aa; L.u[i].y = 0.f; }
+        }
+    }
+    const int od = Tk.obs_mode == 1 ? 21 : 33;
+    const int row = od + 2;
+    const int fs = Tk.frame_skip;
+    const int live_envs = max(0, min(QGK_PAIR_ENVS, n - env0));
+    const int total = live_envs * row;
+    const bool lead = live && half == 0;
+    float *srow = tile + el * 35;
+    const size_t slot_act = (size_t)n * 12, slot_out = (size_t)n * row;
+    float ctrl_reg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float a_next[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool have_next = false;
+
+    for (int kstep = 0; kstep < R.count; ++kstep) {
+        float a_in[6];
+        const float *ap = R.actions + (size_t)kstep * slot_act + (size_t)env * 12 + 6 * half;
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) a_in[c6] = have_next ? a_next[c6] : ap[c6];
+        have_next = kstep + 1 < R.count;
+        if (have_next) {
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) a_next[c6] = ap[slot_act + c6];
+        }
+        float aclip[6];
+        float ssq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float a = fminf(fmaxf(a_in[3 * c + i], -1.f), 1.f);    // quadruped.py:160
+                aclip[3 * c + i] = a;
+                ssq = fmaf(a, a, ssq);
+                const float uu = fminf(fmaxf(a, C.link[i].ctrl_lo), C.link[i].ctrl_hi);
+                if (c == 0) L.u[i].x = uu; else L.u[i].y = uu;
+            }
+        }
+        ssq = pair_sum(ssq);
+        quat_unit(B);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sincos_f(L.q[i] - f2(C.link[i].ref), L.sc[2 * i], L.sc[2 * i + 1]);
+        float zaxis_z = 1.f;
+#pragma unroll 1
+        for (int s = 0; s < fs; ++s) substep_pair(C, cm, sm, B, L, s == fs - 1, srow, half, zaxis_z);
+        nstep += fs;
+        asm volatile("" : "+v"(env));
+
+        const float c_fwd = Tk.w_forward * B.vw.x;
+        const float c_ctl = Tk.w_ctrl * ssq;
+        const float c_alive = Tk.alive_bonus;
+        const float reward = reward_total(c_fwd, c_ctl, c_alive);
+        bool done = nstep >= Tk.limit_substeps;
+        if (Tk.use_fall) done = done || (B.pw.z < Tk.fall_height);
+        {
+            float probe = hsum(L.q[0]) + hsum(L.q[1]) + hsum(L.q[2]) + hsum(L.qd[0]) + hsum(L.qd[1]) + hsum(L.qd[2]);
+            probe = pair_sum(probe) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+            done = done || state_is_bad(probe);
+        }
+        if (Tk.use_flip) done = done || (zaxis_z < 0.f);
+        if (half == 0) {
+            if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }
+            srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f;
+        }
+        wave_sync();
+        {
+            float *dst = R.packed + (size_t)kstep * slot_out + (size_t)env0 * row;
+            if (row == 35) {
+                for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+            } else {
+                const unsigned magic = row == 23 ? 2850u : (65536u + row - 1) / row;
+                for (int e = lane; e < total; e += QGK_WAVE) {
+                    const int er = (int)(((unsigned)e * magic) >> 16), ec = e - er * row;
+                    dst[e] = tile[er * 35 + ec];
+                }
+            }
+        }
+        wave_sync();
+        const bool rst = done && Tk.auto_reset;
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) ctrl_reg[c6] = aclip[c6];
+        if (rst) {
+            B.pw = v3<float>(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+            B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+            if (Tk.reset_flags & 1u) {
+                float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)episode);
+                float sn, cs;
+                sincos_f(0.5f * a, sn, cs);
+                B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+            }
+            B.vw = v3<float>(0.f, 0.f, 0.f);
+            B.wb = v3<float>(0.f, 0.f, 0.f);
+            nstep = 0;
+            episode += 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                L.q[i] = f2(C.qpos0[7 + i]); L.qd[i] = f2(0.f); L.act[i] = f2(0.f);
+            }
+#pragma unroll
+            for (int c6 = 0; c6 < 6; ++c6) ctrl_reg[c6] = Tk.default_ctrl[6 * half + c6];
+        }
+    }
+
+    if (lead) {
+        P.st.qpos[0 * n + env] = B.pw.x; P.st.qpos[1 * n + env] = B.pw.y; P.st.qpos[2 * n + env] = B.pw.z;
+        P.st.qpos[3 * n + env] = B.qw; P.st.qpos[4 * n + env] = B.qx; P.st.qpos[5 * n + env] = B.qy; P.st.qpos[6 * n + env] = B.qz;
+        P.st.qvel[0 * n + env] = B.vw.x; P.st.qvel[1 * n + env] = B.vw.y; P.st.qvel[2 * n + env] = B.vw.z;
+        P.st.qvel[3 * n + env] = B.wb.x; P.st.qvel[4 * n + env] = B.wb.y; P.st.qvel[5 * n + env] = B.wb.z;
+        P.st.nstep[env] = nstep;
+        P.st.episode[env] = episode;
+    }
+    if (live && R.count > 0) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int j = 3 * (2 * half + c) + i;
+                P.st.qpos[(7 + j) * n + env] = c == 0 ? L.q[i].x : L.q[i].y;
+                P.st.qvel[(6 + j) * n + env] = c == 0 ? L.qd[i].x : L.qd[i].y;
+                P.st.act[j * n + env] = c == 0 ? L.act[i].x : L.act[i].y;
+                if (P.track_ctrl) P.st.ctrl[j * n + env] = ctrl_reg[3 * c + i];
+            }
+        }
+    }
+}
+
+// ---- ... and for the one-leg-per-lane kernel (4 097 .. 16 384 envs at one wave per SIMD, 32 769 .. 57 343 at two; any model numbers) ------
+// qg_step_kernel_quad's plain path with an outer loop over env-steps; WPE / BAKED choose the same substep instantiation the per-launch
+// launcher picks for the grid, so the bits are the per-launch kernel's.  Four-wave workgroups (every grid AUTO gives this mapping).
+template <int WPE, bool BAKED>
+__global__ __launch_bounds__(QGK_WAVE * 4, WPE) void qg_step_kernel_quad_multi(const KModel *__restrict__ Mp, const KTask *__restrict__ T, KStepArgs P, KResident R) {
+    constexpr int WAVES = 4;
+    __shared__ float tile_all[WAVES][QGK_QUAD_ENVS * 35];
+    __shared__ KModel smodel;
+    const int lane = threadIdx.x & (QGK_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    float *tile = tile_all[wave];
+    if constexpr (!BAKED) {
+        const float *src = reinterpret_cast<const float *>(Mp);
+        float *dst = reinterpret_cast<float *>(&smodel);
+        for (int i = threadIdx.x; i < (int)(sizeof(KModel) / sizeof(float)); i += QGK_WAVE * WAVES) dst[i] = src[i];
+        __syncthreads();
+    }
+    const KModel &C = BAKED ? QG_BAKED_MODEL : smodel;
+    const int k = lane & 3;
+    const int el = lane >> 2;
+    const int env0 = (blockIdx.x * WAVES + wave) * QGK_QUAD_ENVS;
+    const int n = P.n;
+    const bool live = env0 + el < n;
+    const int env = live ? env0 + el : n - 1;
+    const float cm = (k == 0) ? 1.f : (k == 2) ? -1.f : 0.f;
+    const float sm = (k == 1) ? 1.f : (k == 3) ? -1.f : 0.f;
+    struct { int32_t frame_skip, limit_substeps, use_fall, use_flip, obs_mode, auto_reset; uint32_t reset_flags; float fall_height, w_forward, w_ctrl, alive_bonus;
+             const float *default_ctrl; } Tk = {T->frame_skip, T->limit_substeps, T->use_fall, T->use_flip, T->obs_mode, T->auto_reset, T->reset_flags,
+                                               T->fall_height, T->w_forward, T->w_ctrl, T->alive_bonus, T->default_ctrl};
+
+    BaseState B;
+    B.pw = v3(P.st.qpos[0 * n + env], P.st.qpos[1 * n + env], P.st.qpos[2 * n + env]);
+    B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
+    B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
+    B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
+    int nstep = P.st.nstep[env];
+    int episode = P.st.episode[env];
+    LegState L;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = 3 * k + i;
+        L.q[i] = P.st.qpos[(7 + j) * n + env];
+        L.qd[i] = P.st.qvel[(6 + j) * n + env];
+        L.act[i] = P.st.act[j * n + env];
+        L.u[i] = 0.f; L.sc[2 * i] = 0.f; L.sc[2 * i + 1] = 1.f;
+    }
+    const int od = Tk.obs_mode == 1 ? 21 : 33;
+    const int row = od + 2;
+    const int fs = Tk.frame_skip;
+    const int live_envs = max(0, min(QGK_QUAD_ENVS, n - env0));
+    const int total = live_envs * row;
+    float *srow = tile + el * 35;
+    const size_t slot_act = (size_t)n * 12, slot_out = (size_t)n * row;
+    float ctrl_reg[3] = {0.f, 0.f, 0.f}, a_next[3] = {0.f, 0.f, 0.f};
+    bool have_next = false;
+
+    for (int kstep = 0; kstep < R.count; ++kstep) {
+        const float *ap = R.actions + (size_t)kstep * slot_act + (size_t)env * 12 + 3 * k;
+        float aclip[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float a_in = have_next ? a_next[i] : ap[i];
+            const float a = fminf(fmaxf(a_in, -1.f), 1.f);    // quadruped.py:160
+            aclip[i] = a;
+            L.u[i] = fminf(fmaxf(a, link_of<BAKED>(C, k, i).ctrl_lo), link_of<BAKED>(C, k, i).ctrl_hi);
+        }
+        have_next = WPE == 1 && kstep + 1 < R.count;     // (two waves per SIMD: no registers to park the next action in; the partner covers the load)
+        if (have_next) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a_next[i] = ap[slot_act + i];
+        }
+        quat_unit(B);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sincos_f(L.q[i] - link_of<BAKED>(C, k, i).ref, L.sc[2 * i], L.sc[2 * i + 1]);
+        float zaxis_z = 1.f;
+        asm volatile(".p2align 6");
+#pragma unroll 1
+        for (int s = 0; s < fs; ++s) substep_quad<BAKED, (WPE > 1)>(C, cm, sm, B, L, s == fs - 1, srow, k, zaxis_z);
+        nstep += fs;
+
+        float ssq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ssq = fmaf(aclip[i], aclip[i], ssq);
+        ssq = quad_sum(ssq);
+        const float c_fwd = Tk.w_forward * B.vw.x;
+        const float c_ctl = Tk.w_ctrl * ssq;
+        const float c_alive = Tk.alive_bonus;
+        const float reward = reward_total(c_fwd, c_ctl, c_alive);
+        bool done = nstep >= Tk.limit_substeps;
+        if (Tk.use_fall) done = done || (B.pw.z < Tk.fall_height);
+        {
+            float probe = L.q[0] + L.q[1] + L.q[2] + L.qd[0] + L.qd[1] + L.qd[2];
+            probe = quad_sum(probe) + B.pw.x + B.pw.y + B.pw.z + B.qw + B.vw.x + B.vw.y + B.vw.z + B.wb.x + B.wb.y + B.wb.z;
+            done = done || state_is_bad(probe);
+        }
+        if (Tk.use_flip) done = done || (zaxis_z < 0.f);
+        if (k == 0) {
+            if (od == 21) { srow[18] = srow[30]; srow[19] = srow[31]; srow[20] = srow[32]; }
+            srow[od] = reward; srow[od + 1] = done ? 1.f : 0.f;
+        }
+        wave_sync();
+        {
+            float *dst = R.packed + (size_t)kstep * slot_out + (size_t)env0 * row;
+            if (row == 35) {
+                for (int e = lane; e < total; e += QGK_WAVE) dst[e] = tile[e];
+            } else {
+                const unsigned magic = row == 23 ? 2850u : (65536u + row - 1) / row;
+                for (int e = lane; e < total; e += QGK_WAVE) {
+                    const int er = (int)(((unsigned)e * magic) >> 16), ec = e - er * row;
+                    dst[e] = tile[er * 35 + ec];
+                }
+            }
+        }
+        wave_sync();
+        const bool rst = done && Tk.auto_reset;
+        if constexpr (WPE == 1) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ctrl_reg[i] = aclip[i];
+        } else if (live && P.track_ctrl) {      // two waves per SIMD: data.ctrl goes out every env-step (as the per-launch kernel writes it) rather
+#pragma unroll                                  // than riding through the substep loop in three more registers
+            for (int i = 0; i < 3; ++i) P.st.ctrl[(3 * k + i) * n + env] = rst ? Tk.default_ctrl[3 * k + i] : aclip[i];
+        }
+        if (rst) {
+            B.pw = v3(C.qpos0[0], C.qpos0[1], C.qpos0[2]);
+            B.qw = C.qpos0[3]; B.qx = C.qpos0[4]; B.qy = C.qpos0[5]; B.qz = C.qpos0[6];
+            if (Tk.reset_flags & 1u) {
+                float a = 6.283185307179586f * uniform24(P.seed, P.env_index_base + (uint64_t)env, (uint64_t)episode);
+                float sn, cs;
+                sincos_f(0.5f * a, sn, cs);
+                B.qw = cs; B.qx = 0.f; B.qy = 0.f; B.qz = sn;
+            }
+            B.vw = v3(0.f, 0.f, 0.f);
+            B.wb = v3(0.f, 0.f, 0.f);
+            nstep = 0;
+            episode += 1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                L.q[i] = C.qpos0[7 + (BAKED ? i : 3 * k + i)]; L.qd[i] = 0.f; L.act[i] = 0.f;
+                if constexpr (WPE == 1) ctrl_reg[i] = Tk.default_ctrl[3 * k + i];
+            }
+        }
+    }
+
+    // the addresses of the final stores are derived from (env, leg) AFTER the loops: visible to the optimiser they are computed ahead of
+    // them and carried through the substep loop (qg_step_kernel_quad does the same for its epilogue)
+    int env_e = env, k_e = k;
+    asm volatile("" : "+v"(env_e), "+v"(k_e));
+    if (live && k_e == 0) {
+        P.st.qpos[0 * n + env_e] = B.pw.x; P.st.qpos[1 * n + env_e] = B.pw.y; P.st.qpos[2 * n + env_e] = B.pw.z;
+        P.st.qpos[3 * n + env_e] = B.qw; P.st.qpos[4 * n + env_e] = B.qx; P.st.qpos[5 * n + env_e] = B.qy; P.st.qpos[6 * n + env_e] = B.qz;
+        P.st.qvel[0 * n + env_e] = B.vw.x; P.st.qvel[1 * n + env_e] = B.vw.y; P.st.qvel[2 * n + env_e] = B.vw.z;
+        P.st.qvel[3 * n + env_e] = B.wb.x; P.st.qvel[4 * n + env_e] = B.wb.y; P.st.qvel[5 * n + env_e] = B.wb.z;
+        P.st.nstep[env_e] = nstep;
+        P.st.episode[env_e] = episode;
+    }
+    if (live && R.count > 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int j = 3 * k_e + i;
+            P.st.qpos[(7 + j) * n + env_e] = L.q[i];
+            P.st.qvel[(6 + j) * n + env_e] = L.qd[i];
+            P.st.act[j * n + env_e] = L.act[i];
+            if (WPE == 1 && P.track_ctrl) P.st.ctrl[j * n + env_e] = ctrl_reg[i];
+        }
     }
 }

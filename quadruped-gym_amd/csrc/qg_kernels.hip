@@ -380,6 +380,28 @@ template <class T> DEV void add_rigid(Sym6T<T> &A, const RigidT<T> &B) {
 
 struct BaseState { V3 pw; float qw, qx, qy, qz; V3 vw; V3 wb; };
 
+// forward + control_cost + alive_bonus (README.md:65-72) -- `c_fwd` = w_forward * qvel[0] and `c_ctl` = w_ctrl * sum(ctrl^2) are products,
+// and a sum of two products is where the compiler's contraction has a choice (fma(a, b, c*d) or fma(c, d, a*b)): the per-launch and the
+// many-steps-per-launch forms of the two-legs-per-lane kernel made different ones (round 4: rewards one ulp apart in a fifth of the envs).
+// Written out: no contraction in here, every kernel adds the two rounded products and then the bonus.
+DEV float reward_total(float c_fwd, float c_ctl, float c_alive) {
+#pragma clang fp contract(off)
+    return (c_fwd + c_ctl) + c_alive;
+}
+
+// The quaternion scaled to unit length at the head of an env-step.  The sum of squares is written out as explicit multiply-adds: left
+// to the compiler's contraction, w*w + x*x may become fma(w, w, x*x) in one kernel and fma(x, x, w*w) in another (it did: the
+// per-launch kernel and the many-steps-per-launch kernel of qg_kernel_resident.hip differed by one ulp in a few envs per step),
+// and those two kernels must leave the same bits.
+DEV void quat_unit(BaseState &B) {
+    float d = B.qx * B.qx;
+    d = fmaf(B.qw, B.qw, d);
+    d = fmaf(B.qy, B.qy, d);
+    d = fmaf(B.qz, B.qz, d);
+    const float qn = __builtin_amdgcn_rsqf(d);
+    B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
+}
+
 // quantities of one substep that depend on the base state only
 struct BaseCtx {
     float w, x, y, z;       // normalised quaternion
@@ -903,7 +925,7 @@ __global__ __launch_bounds__(QGK_WAVE) void qg_step_kernel(const KModel *__restr
     float c_fwd = T->w_forward * B.vw.x;
     float c_ctl = T->w_ctrl * ssq;
     float c_alive = T->alive_bonus;
-    float reward = c_fwd + c_ctl + c_alive;
+    float reward = reward_total(c_fwd, c_ctl, c_alive);
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
     if (T->use_flip) done = done || (so.zaxis.z < 0.f);          // walking_quad.py:156-160, on the step's sensordata
@@ -1283,10 +1305,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
     B.vw = v3(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
-    {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised (base_prelude<UNIT>)
-        const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
-        B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
-    }
+    quat_unit(B);   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised (base_prelude<UNIT>)
     LegState L;
     const int nstep0 = P.st.nstep[env];
     float aclip0[3];
@@ -1412,7 +1431,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES * (HELP ? 2 : 1), WPE) void qg_ste
     float c_fwd = T->w_forward * B.vw.x;
     float c_ctl = T->w_ctrl * ssq;
     float c_alive = T->alive_bonus;
-    float reward = c_fwd + c_ctl + c_alive;
+    float reward = reward_total(c_fwd, c_ctl, c_alive);
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
     {
@@ -1720,10 +1739,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     B.qw = P.st.qpos[3 * n + env]; B.qx = P.st.qpos[4 * n + env]; B.qy = P.st.qpos[5 * n + env]; B.qz = P.st.qpos[6 * n + env];
     B.vw = v3<float>(P.st.qvel[0 * n + env], P.st.qvel[1 * n + env], P.st.qvel[2 * n + env]);
     B.wb = v3<float>(P.st.qvel[3 * n + env], P.st.qvel[4 * n + env], P.st.qvel[5 * n + env]);
-    {   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised (base_prelude<UNIT>)
-        const float qn = __builtin_amdgcn_rsqf(B.qw * B.qw + B.qx * B.qx + B.qy * B.qy + B.qz * B.qz);
-        B.qw *= qn; B.qx *= qn; B.qy *= qn; B.qz *= qn;
-    }
+    quat_unit(B);   // unit quaternion once per launch (qg_set_state may hand in any length); the substeps keep it normalised (base_prelude<UNIT>)
     int nstep = P.st.nstep[env];
     LegPair L;
     float aclip[6];
@@ -1845,7 +1861,7 @@ __global__ __launch_bounds__(QGK_WAVE * WAVES, 1) void qg_step_kernel_pair(const
     float c_fwd = T->w_forward * B.vw.x;
     float c_ctl = T->w_ctrl * ssq;
     float c_alive = T->alive_bonus;
-    float reward = c_fwd + c_ctl + c_alive;
+    float reward = reward_total(c_fwd, c_ctl, c_alive);
     bool done = nstep >= T->limit_substeps;
     if (T->use_fall) done = done || (B.pw.z < T->fall_height);
     {

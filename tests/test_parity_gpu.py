@@ -864,3 +864,22 @@ def test_random_task_and_model_variants_match_oracle(oracle, trial):
         close(comps, comps_o, t["reward"], what + "reward components")
         sure = np.abs(q_o[:, 2] - gtask.fall_height) > 1e-4
         assert np.array_equal(np.asarray(done)[sure], done_o[sure])
+
+
+@pytest.mark.parametrize("mapping,n", [("link", 700), ("quad", 700), ("pair", 700), ("lane", 700)])
+def test_reward_is_the_f32_sum_of_its_components_in_every_kernel(mapping, n):
+    """``total_reward += fn()`` over the reward dict (quadruped.py:170-175) in f32: every step kernel adds the rounded products
+    ``forward + control_cost`` and then ``alive_bonus`` with no multiply-add contraction (reward_total, round 4), so the reward a step
+    reports IS the sum of the components it reports, to the bit, whatever the mapping and the weights."""
+    from quadruped_gym_amd.sim import BatchedSim
+    task = configure(_abi.default_task(), "A")
+    task.w_forward, task.w_ctrl, task.alive_bonus = 0.7, -0.37, 0.3
+    sim = BatchedSim(n, task=task)
+    sim.set_mapping(MAPPINGS[mapping])
+    sim.reset(seed=4)
+    rng = np.random.default_rng(12)
+    for _ in range(30):
+        obs, rew, done, comps = sim.step(rng.uniform(-1, 1, (n, 12)).astype(np.float32), want_components=True)
+        want = (comps[:, 0] + comps[:, 1]).astype(np.float32) + comps[:, 2]
+        assert np.array_equal(rew, want.astype(np.float32))
+    sim.close()

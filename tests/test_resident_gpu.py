@@ -31,7 +31,8 @@ def _task(frame_skip=4, imu=False, max_time=0.2, yaw=True):
 def _twin(n, task, seed=5):
     from quadruped_gym_amd.sim import BatchedSim
     a, b = BatchedSim(n, task=task), BatchedSim(n, task=task)
-    assert a.mapping == _abi.MAP_LINK
+    want = _abi.MAP_LINK if n <= 4096 else _abi.MAP_QUAD if (n <= 16384 or 32768 < n < 57344) else _abi.MAP_PAIR
+    assert a.mapping == want
     a.reset(seed=seed, flags=task.reset_flags); b.reset(seed=seed, flags=task.reset_flags)
     return a, b
 
@@ -51,12 +52,17 @@ def _same_state(a, b):
     return ea[0]
 
 
-@pytest.mark.parametrize("n,fs,imu", [(4096, 4, False), (1000, 4, False), (3, 20, True), (4096, 20, True)])
+@pytest.mark.parametrize("n,fs,imu", [(4096, 4, False), (1000, 4, False), (3, 20, True), (4096, 20, True),
+                                      # the two-legs-per-lane mapping's own one-launch form (BASELINE configs 3 / 4's sizes; one- and
+                                      # four-wave workgroups, a ragged last wave, the 21-value pack)
+                                      (32768, 4, False), (20001, 4, True), (16400, 8, False), (60000, 4, False),
+                                      # ... and the one-leg-per-lane mapping's (one wave per SIMD: 4 097 .. 16 384 envs; two: 32 769 .. 57 343)
+                                      (8192, 4, False), (12001, 20, True), (40000, 4, False)])
 def test_sequence_launch_is_bit_identical_to_per_step_launches(n, fs, imu):
     """ONE launch of K env-steps against K launches of the per-launch kernel: same packed rows, same final state, same episode
     counters -- through auto-resets with random yaw (25 or 5 env-steps per episode), a ragged last workgroup, both observation packs."""
     import torch
-    K, rounds = 24, 4
+    K, rounds = (24, 4) if n <= 4096 else (12, 3)
     task = _task(fs, imu)
     a, b = _twin(n, task)
     dev = torch.device("cuda:0")
@@ -72,9 +78,10 @@ def test_sequence_launch_is_bit_identical_to_per_step_launches(n, fs, imu):
         torch.cuda.synchronize()
         assert torch.equal(pa, pb), rnd
         finished += int(pa[:, :, -1].sum())
-    assert finished >= 2 * n
+    episodes = 2 if n <= 4096 else 1                  # (the large batches run 36 env-steps: one time limit of 25, or of 12 - 13 at frame_skip 8 / 20)
+    assert finished >= episodes * n
     ep = _same_state(a, b)
-    assert ep.min() >= 2
+    assert ep.min() >= episodes
     a.close(); b.close()
 
 
@@ -338,22 +345,29 @@ def test_sequence_and_resident_forms_with_other_model_numbers():
     """Any other robot (here: one mass and one servo gain changed) runs the variants that stage the model tables in LDS
     (``qg_step_kernel_link_multi<BAKED = false, ..>``): the sequence launch and closed-loop rings against per-step launches of the same
     tables, bit for bit, through auto-resets."""
+    _other_model_numbers(1500, True)
+    _other_model_numbers(6000, False)
+
+
+def _other_model_numbers(n, with_ring):
     import torch
     from quadruped_gym_amd.sim import BatchedSim
-    n, K = 1500, 16
+    K = 16
     model = _abi.default_model()
     model.body_mass[3] *= 1.25
     model.act_kp[1] = 85.0
     task = _task()
-    sims = [BatchedSim(n, model=model, task=task) for _ in range(3)]
-    seq, ring, ref = sims
+    sims = [BatchedSim(n, model=model, task=task) for _ in range(3 if with_ring else 2)]
+    seq, ref = sims[0], sims[-1]
+    ring = sims[1] if with_ring else None
     for s in sims:
-        assert not s.baked and s.mapping == _abi.MAP_LINK
+        assert not s.baked and s.mapping == (_abi.MAP_LINK if n <= 4096 else _abi.MAP_QUAD)
         s.reset(seed=2, flags=task.reset_flags)
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev); gen.manual_seed(6)
     mail_a = torch.zeros((1, n, 12), device=dev); mail_p = torch.zeros((1, n, 35), device=dev)
-    ring.resident_start(mail_a, mail_p)
+    if with_ring:
+        ring.resident_start(mail_a, mail_p)
     finished = 0
     for rnd in range(4):
         acts = torch.rand((K, n, 12), generator=gen, device=dev) * 2 - 1
@@ -361,14 +375,18 @@ def test_sequence_and_resident_forms_with_other_model_numbers():
         seq.step_device_seq(acts, ps)
         for k in range(K):
             ref.step_device_packed(acts[k], pr[k])
-            mail_a[0].copy_(acts[k])
-            ring.resident_step(1)
-            pg[k].copy_(mail_p[0])
+            if with_ring:
+                mail_a[0].copy_(acts[k])
+                ring.resident_step(1)
+                pg[k].copy_(mail_p[0])
         _sync()
-        assert torch.equal(ps, pr) and torch.equal(pg, pr), rnd
+        assert torch.equal(ps, pr) and (not with_ring or torch.equal(pg, pr)), rnd
         finished += int(pr[:, :, -1].sum())
-    assert finished >= 2 * n and ring.resident_status()["not_executed"] == 0
-    _same_state(seq, ref); _same_state(ring, ref)
-    ring.resident_stop()
+    assert finished >= 2 * n
+    _same_state(seq, ref)
+    if with_ring:
+        assert ring.resident_status()["not_executed"] == 0
+        _same_state(ring, ref)
+        ring.resident_stop()
     for s in sims:
         s.close()

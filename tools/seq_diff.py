@@ -4,8 +4,10 @@ import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from quadruped_gym_amd import _abi
 from quadruped_gym_amd.sim import BatchedSim
-n, K = 4096, 8
+n, K = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 8
 t = _abi.default_task(); t.auto_reset = 1; t.max_time = 0.2; t.use_fall = 1; t.fall_height = 0.05; t.reset_flags = 1
+import os
+t.w_forward = float(os.environ.get("QG_W_FORWARD", "1.0")); t.w_ctrl = float(os.environ.get("QG_W_CTRL", "-0.1")); t.alive_bonus = float(os.environ.get("QG_ALIVE", "1.0"))
 a, b = BatchedSim(n, task=t), BatchedSim(n, task=t)
 a.reset(seed=5, flags=1); b.reset(seed=5, flags=1)
 dev = torch.device("cuda:0")
