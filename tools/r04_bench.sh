@@ -12,6 +12,10 @@ python bench.py --seq 64 --no-cpu-baseline > $B/bench_cfg2_seq64.json 2>/dev/nul
 python bench.py --resident ahead --no-cpu-baseline > $B/bench_cfg2_resident_ahead.json 2>/dev/null; echo "resident ahead rc=$?"
 python bench.py --resident closed --no-cpu-baseline > $B/bench_cfg2_resident_closed.json 2>/dev/null; echo "resident closed rc=$?"
 python bench.py --envs-per-gpu 32768 --random-yaw --steps 1000 --warmup 100 --cpu-seconds 3 > $B/bench_cfg3.json 2>/dev/null; echo "cfg3 rc=$?"
+python bench.py --envs-per-gpu 32768 --random-yaw --seq 16 --steps 992 --no-cpu-baseline > $B/bench_cfg3_seq16.json 2>/dev/null; echo "cfg3 seq rc=$?"
+python bench.py --envs-per-gpu 16384 --steps 992 --no-cpu-baseline > $B/bench_n16384.json 2>/dev/null; echo "16384 rc=$?"
+python bench.py --envs-per-gpu 16384 --seq 16 --steps 992 --no-cpu-baseline > $B/bench_n16384_seq16.json 2>/dev/null; echo "16384 seq rc=$?"
+python bench.py --envs-per-gpu 262144 --random-yaw --seq 16 --steps 208 --warmup 16 --no-cpu-baseline > $B/bench_cfg4_total_one_gpu_seq16.json 2>/dev/null; echo "cfg4 seq rc=$?"
 python bench.py --envs-per-gpu 262144 --random-yaw --steps 200 --warmup 20 --no-cpu-baseline > $B/bench_cfg4_total_one_gpu.json 2>/dev/null; echo "cfg4 rc=$?"
 python bench.py --frame-skip 20 --obs-mode 1 --steps 1000 --warmup 100 --cpu-seconds 3 > $B/bench_cfg5.json 2>/dev/null; echo "cfg5 rc=$?"
 python bench.py --frame-skip 20 --obs-mode 1 --seq 16 --steps 1008 --no-cpu-baseline > $B/bench_cfg5_seq16.json 2>/dev/null; echo "cfg5 seq rc=$?"

@@ -3,7 +3,7 @@
 # r04_profiles.sh, or in the build container on the merged gpurun_out/)
 cd /root/repo
 mkdir -p profiles/r04
-for t in link_n4096 pair_n32768_yaw link_n4096_fs20_imu walking_n4096 quad_n4096 pair_n262144_yaw seq16_n4096; do
+for t in link_n4096 pair_n32768_yaw link_n4096_fs20_imu walking_n4096 quad_n4096 pair_n262144_yaw seq16_n4096 seq16_n32768_yaw; do
   [ -d gpurun_out/prof_r04_$t ] && python tools/summarize_profile.py gpurun_out/prof_r04_$t profiles/r04/$t > /dev/null
 done
 if [ "${1:-}" != profiles-only ]; then

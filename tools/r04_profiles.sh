@@ -11,5 +11,6 @@ tools/profile_gpu.sh r04_walking_n4096 --walking
 tools/profile_gpu.sh r04_quad_n4096 --mapping quad
 tools/profile_gpu.sh r04_pair_n262144_yaw --envs-per-gpu 262144 --random-yaw --steps 100
 tools/profile_gpu.sh r04_seq16_n4096 --seq 16
+tools/profile_gpu.sh r04_seq16_n32768_yaw --envs-per-gpu 32768 --random-yaw --seq 16
 bash tools/r04_collect.sh profiles-only
 mkdir -p gpurun_out/r04_final && cp -r profiles/r04 profiles/traffic_index.json gpurun_out/r04_final/
