@@ -2,6 +2,7 @@
 """Compare the kernels of two device listings (hipcc -save-temps .s files) instruction by instruction.
 
 usage: asm_diff.py <base.s> <new.s> [substring of the mangled names to look at]
+       asm_diff.py --loops <base.s> <new.s> [substring]     compare only each kernel's substep loop (the loop with the most multiply-adds)
 Labels are renumbered per kernel (.LBB<function index>_<n> changes when kernels are added or removed elsewhere in the code object);
 comments, .loc / .file / .cfi directives and blank lines are ignored.  Prints one line per kernel: identical / differs (first
 differing instruction) / only in one listing."""
@@ -30,8 +31,34 @@ def kernels(path):
     return out
 
 
+def loops(path):
+    """kernel name -> instructions of its substep loop (asm_hist.largest_loop on the raw listing), labels renumbered"""
+    sys.path.insert(0, __file__.rsplit("/", 1)[0])
+    from asm_hist import kernel_lines, largest_loop
+    out = {}
+    for k in kernels(path):
+        if "qg_step_kernel" not in k:
+            continue
+        try:
+            lp = largest_loop(kernel_lines(path, k))
+        except Exception:
+            continue
+        body = []
+        for ln in lp or []:
+            t = ln.split(";")[0].strip()
+            if not t or t.startswith("."):
+                continue
+            body.append(re.sub(r"\.LBB\d+_", ".LBB_", t))
+        if body:
+            out[k] = body
+    return out
+
+
 def main():
-    a, b = kernels(sys.argv[1]), kernels(sys.argv[2])
+    only_loops = len(sys.argv) > 1 and sys.argv[1] == "--loops"
+    if only_loops:
+        sys.argv.pop(1)
+    a, b = (loops if only_loops else kernels)(sys.argv[1]), (loops if only_loops else kernels)(sys.argv[2])
     key = sys.argv[3] if len(sys.argv) > 3 else ""
     same = diff = 0
     for k in sorted(set(a) | set(b)):
