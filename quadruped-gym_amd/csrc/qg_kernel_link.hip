@@ -107,6 +107,7 @@ DEV V3 leg_prefix(V3 a) { return v3(leg_prefix(a.x), leg_prefix(a.y), leg_prefix
 // what link r needs as per-lane data (registers)
 struct LinkRegs {
     float mass, ipos[3], inertia[6], cp[QGK_CP_LINK][3];
+    f2 cp2[QGK_CP_LINK / 2][3];     // the same sample points as packed pairs (i, i + 4): what the compiled-in robot's substep reads
     float lo, hi, damping, armature, kp, kv, gear, force_lo, force_hi, act_decay;
     float cpF[3];       // this lane's sample point of the FRAME (one of its twelve; the spare lanes carry none)
     float ml;           // 1 in the lanes that own a link, 0 in the spare lane
@@ -133,6 +134,7 @@ DEV V3 sel3(int r, V3 a, V3 b, V3 c) { return v3(sel3(r, a.x, b.x, c.x), sel3(r,
 template <bool BAKED>
 DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env, BaseState &B, HingeLane &J, const LinkRegs &K,
                       bool want_sensors, float *__restrict__ row, int kleg, float &zaxis_z) {
+    using namespace pk3;
     const float h = C.h;
     const BaseCtx bc = base_prelude<true>(C, B);     // the quaternion is of unit length here (normalised at load, then by base_integrate)
     const V3 nb = bc.n;
@@ -201,12 +203,15 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         V3 uy = fma3(K.inertia[3], E.ex, fma3(K.inertia[1], E.ey, K.inertia[5] * E.ez));
         V3 uz = fma3(K.inertia[4], E.ex, fma3(K.inertia[5], E.ey, K.inertia[2] * E.ez));
         float hc = dot(Bi.h, c);
-        Bi.I.xx = fmaf(ux.x, E.ex.x, fmaf(uy.x, E.ey.x, uz.x * E.ez.x)) + hc - Bi.h.x * c.x;
-        Bi.I.yy = fmaf(ux.y, E.ex.y, fmaf(uy.y, E.ey.y, uz.y * E.ez.y)) + hc - Bi.h.y * c.y;
+        // (xx, yy) and (xz, yz) as packed pairs: the (x, y) halves of ux, uy, uz, the axes, h and c are the pairs the operators above made
+        const f2 uxp = {ux.x, ux.y}, uyp = {uy.x, uy.y}, uzp = {uz.x, uz.y}, hp = {Bi.h.x, Bi.h.y}, cp2 = {c.x, c.y};
+        const f2 d2 = __builtin_elementwise_fma(uxp, f2{E.ex.x, E.ex.y}, __builtin_elementwise_fma(uyp, f2{E.ey.x, E.ey.y}, uzp * f2{E.ez.x, E.ez.y}))
+                      + f2{hc, hc} - hp * cp2;
+        const f2 o2 = __builtin_elementwise_fma(uxp, f2{E.ex.z, E.ex.z}, __builtin_elementwise_fma(uyp, f2{E.ey.z, E.ey.z}, uzp * f2{E.ez.z, E.ez.z}))
+                      - hp * f2{c.z, c.z};
+        Bi.I.xx = d2.x; Bi.I.yy = d2.y; Bi.I.xz = o2.x; Bi.I.yz = o2.y;
         Bi.I.zz = fmaf(ux.z, E.ex.z, fmaf(uy.z, E.ey.z, uz.z * E.ez.z)) + hc - Bi.h.z * c.z;
         Bi.I.xy = fmaf(ux.x, E.ex.y, fmaf(uy.x, E.ey.y, uz.x * E.ez.y)) - Bi.h.x * c.y;
-        Bi.I.xz = fmaf(ux.x, E.ex.z, fmaf(uy.x, E.ey.z, uz.x * E.ez.z)) - Bi.h.x * c.z;
-        Bi.I.yz = fmaf(ux.y, E.ex.z, fmaf(uy.y, E.ey.z, uz.y * E.ez.z)) - Bi.h.y * c.z;
     }
     SV f;
     {
@@ -221,8 +226,21 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         float wsum = 0.f;
         V3 s = v3(0.f, 0.f, 0.f);
         const float zb = C.contact_margin - zo;
+        if constexpr (BAKED) {   // the eight sample points two at a time as packed FP32 (points i and i + 4 of the lane's register-held constants share an
+            // instruction; the two partial sums are added at the end): 36 + 4 instructions for 64
+            static_assert(QGK_CP_LINK % 2 == 0, "sample points are taken in pairs");
+            f2 w2 = {0.f, 0.f};
+            V3T<f2> s2 = v3<f2>(w2, w2, w2);
+            const V3T<f2> nl2 = v3<f2>(f2{nl.x, nl.x}, f2{nl.y, nl.y}, f2{nl.z, nl.z});
+            const f2 zb2 = {zb, zb};
 #pragma unroll
-        for (int i = 0; i < QGK_CP_LINK; ++i) contact_point(v3(K.cp[i][0], K.cp[i][1], K.cp[i][2]), nl, zb, wsum, s);
+            for (int i = 0; i < QGK_CP_LINK / 2; ++i) contact_point(v3<f2>(K.cp2[i][0], K.cp2[i][1], K.cp2[i][2]), nl2, zb2, w2, s2);
+            wsum = w2.x + w2.y;
+            s = v3(s2.x.x + s2.x.y, s2.y.x + s2.y.y, s2.z.x + s2.z.y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < QGK_CP_LINK; ++i) contact_point(v3(K.cp[i][0], K.cp[i][1], K.cp[i][2]), nl, zb, wsum, s);
+        }
         wsum *= K.ml;                               // the spare lane is no link (its mass and inertia are zero as well)
         SV fe;
         ContactDampT<float> cd;
@@ -301,20 +319,37 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     // ---- this lane's share of the base block: its own link's inertia and force (summed over the env's lanes they are the legs' composite
     // inertias and forces) minus z z^T / d_r;  F u = sum_r z_r y_r / d_r ----
     const float idr = sel3(rr, id0, id1, id2), yr = sel3(rr, y0, y1, y2);
-    float w[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = idr * z[i];
+    // Packed FP32 (a lone wave pays per instruction issued).  The pairs follow the (x, y) + z split of the packed V3 operators:
+    // P = (z0, z1) and L = (z3, z4) are the xy halves of the angular and linear part, Z = (z2, z5) their z components; no value is
+    // in two pairs, so nothing is copied to form one, and every product takes its halves from ONE pair per operand (op_sel).
+    const f2 P = {z[0], z[1]}, L = {z[3], z[4]}, Z = {z[2], z[5]};
+    const f2 idr2 = {idr, idr};
+    const f2 WP = idr2 * P, WL = idr2 * L, WZ = idr2 * Z;
     Sym6 Cn;
-    Cn.AA.xx = fmaf(-w[0], z[0], A.AA.xx); Cn.AA.yy = fmaf(-w[1], z[1], A.AA.yy); Cn.AA.zz = fmaf(-w[2], z[2], A.AA.zz);
-    Cn.AA.xy = fmaf(-w[0], z[1], A.AA.xy); Cn.AA.xz = fmaf(-w[0], z[2], A.AA.xz); Cn.AA.yz = fmaf(-w[1], z[2], A.AA.yz);
-    Cn.AL.r0 = v3(fmaf(-w[0], z[3], A.AL.r0.x), fmaf(-w[0], z[4], A.AL.r0.y), fmaf(-w[0], z[5], A.AL.r0.z));
-    Cn.AL.r1 = v3(fmaf(-w[1], z[3], A.AL.r1.x), fmaf(-w[1], z[4], A.AL.r1.y), fmaf(-w[1], z[5], A.AL.r1.z));
-    Cn.AL.r2 = v3(fmaf(-w[2], z[3], A.AL.r2.x), fmaf(-w[2], z[4], A.AL.r2.y), fmaf(-w[2], z[5], A.AL.r2.z));
-    Cn.LL.xx = fmaf(-w[3], z[3], A.LL.xx); Cn.LL.yy = fmaf(-w[4], z[4], A.LL.yy); Cn.LL.zz = fmaf(-w[5], z[5], A.LL.zz);
-    Cn.LL.xy = fmaf(-w[3], z[4], A.LL.xy); Cn.LL.xz = fmaf(-w[3], z[5], A.LL.xz); Cn.LL.yz = fmaf(-w[4], z[5], A.LL.yz);
+    {
+        const f2 Zlo = {Z.x, Z.x}, Zhi = {Z.y, Z.y};
+        const f2 WPlo = {WP.x, WP.x}, WPhi = {WP.y, WP.y}, WZlo = {WZ.x, WZ.x};
+        const f2 aa0 = __builtin_elementwise_fma(-WP, P, f2{A.AA.xx, A.AA.yy});            // w0 z0, w1 z1
+        const f2 aa1 = __builtin_elementwise_fma(-WP, Zlo, f2{A.AA.xz, A.AA.yz});          // w0 z2, w1 z2
+        Cn.AA.xx = aa0.x; Cn.AA.yy = aa0.y; Cn.AA.xz = aa1.x; Cn.AA.yz = aa1.y;
+        Cn.AA.xy = fmaf(-WP.x, P.y, A.AA.xy); Cn.AA.zz = fmaf(-WZ.x, Z.x, A.AA.zz);
+        const f2 c0 = __builtin_elementwise_fma(-WPlo, L, f2{A.AL.r0.x, A.AL.r0.y});       // w0 z3, w0 z4
+        const f2 c1 = __builtin_elementwise_fma(-WPhi, L, f2{A.AL.r1.x, A.AL.r1.y});       // w1 z3, w1 z4
+        const f2 c2 = __builtin_elementwise_fma(-WZlo, L, f2{A.AL.r2.x, A.AL.r2.y});       // w2 z3, w2 z4
+        const f2 c3 = __builtin_elementwise_fma(-WP, Zhi, f2{A.AL.r0.z, A.AL.r1.z});       // w0 z5, w1 z5
+        Cn.AL.r0 = v3(c0.x, c0.y, c3.x);
+        Cn.AL.r1 = v3(c1.x, c1.y, c3.y);
+        Cn.AL.r2 = v3(c2.x, c2.y, fmaf(-WZ.x, Z.y, A.AL.r2.z));
+        const f2 l0 = __builtin_elementwise_fma(-WL, L, f2{A.LL.xx, A.LL.yy});             // w3 z3, w4 z4
+        const f2 l1 = __builtin_elementwise_fma(-WL, Zhi, f2{A.LL.xz, A.LL.yz});           // w3 z5, w4 z5
+        Cn.LL.xx = l0.x; Cn.LL.yy = l0.y; Cn.LL.xz = l1.x; Cn.LL.yz = l1.y;
+        Cn.LL.xy = fmaf(-WL.x, L.y, A.LL.xy); Cn.LL.zz = fmaf(-WZ.y, Z.y, A.LL.zz);
+    }
     // right-hand side share: -(f_own + z_r y_r / d_r)
-    SV rhn = {v3(fmaf(-yr, w[0], -f.a.x), fmaf(-yr, w[1], -f.a.y), fmaf(-yr, w[2], -f.a.z)),
-              v3(fmaf(-yr, w[3], -f.l.x), fmaf(-yr, w[4], -f.l.y), fmaf(-yr, w[5], -f.l.z))};
+    const f2 nyr = {-yr, -yr};
+    const f2 rh0 = __builtin_elementwise_fma(nyr, WP, f2{-f.a.x, -f.a.y}), rh1 = __builtin_elementwise_fma(nyr, WL, f2{-f.l.x, -f.l.y}),
+             rh2 = __builtin_elementwise_fma(nyr, WZ, f2{-f.a.z, -f.l.z});
+    SV rhn = {v3(rh0.x, rh0.y, rh2.x), v3(rh1.x, rh1.y, rh2.y)};
     // ---- base block: FRAME body, the sums over the env's 16 lanes, the FRAME's contact (a wave-uniform branch that updates the block
     // in place: on the usual path, no contact, nothing has to be moved), the 6x6 solve -- all redundant in the 16 lanes.  Every DPP
     // move sits in one basic block with the add that consumes it (the compiler fuses them into v_add_f32_dpp only then).

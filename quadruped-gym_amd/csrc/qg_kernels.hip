@@ -103,6 +103,18 @@ template <class T> DEV V3T<T> operator*(T s, V3T<T> a) { return v3<T>(s * a.x, s
 template <class T> DEV T dot(V3T<T> a, V3T<T> b) { return fma_(a.x, b.x, fma_(a.y, b.y, a.z * b.z)); }
 template <class T> DEV V3T<T> cross(V3T<T> a, V3T<T> b) { return v3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 template <class T> DEV V3T<T> fma3(T s, V3T<T> a, V3T<T> b) { return v3<T>(fma_(s, a.x, b.x), fma_(s, a.y, b.y), fma_(s, a.z, b.z)); }
+// Packed FP32 for the kernel that is ALONE on its SIMD (one link per lane, qg_kernel_link.hip): a lone wave issues one VALU instruction
+// per >= 4 cycles whatever it is, so (x, y) of a 3-vector operation as ONE v_pk_*_f32 is an instruction saved (z stays a plain one).
+// At two waves per SIMD a packed instruction costs the two plain ones it replaces (tools/ubench/vgpr_bank), and with the generic
+// robot's register budget the aligned pairs spill -- hence a namespace that only substep_link() opens (`using namespace pk3`: these
+// non-template overloads then win over the templates above), not a change of the templates.  Same arithmetic, same rounding: a
+// packed multiply-add is two IEEE multiply-adds; the compiler takes a broadcast or a swap of a pair's halves as op_sel modifiers.
+namespace pk3 {
+DEV V3 fma3(float s, V3 a, V3 b) { f2 A = {a.x, a.y}, Bv = {b.x, b.y}, S = {s, s}; f2 r = __builtin_elementwise_fma(S, A, Bv); return v3<float>(r.x, r.y, fmaf(s, a.z, b.z)); }
+DEV V3 operator+(V3 a, V3 b) { f2 A = {a.x, a.y}, Bv = {b.x, b.y}; f2 r = A + Bv; return v3<float>(r.x, r.y, a.z + b.z); }
+DEV V3 operator-(V3 a, V3 b) { f2 A = {a.x, a.y}, Bv = {b.x, b.y}; f2 r = A - Bv; return v3<float>(r.x, r.y, a.z - b.z); }
+DEV V3 operator*(float s, V3 a) { f2 A = {a.x, a.y}, S = {s, s}; f2 r = S * A; return v3<float>(r.x, r.y, s * a.z); }
+}  // namespace pk3
 DEV V3 ld3(const float *p) { return v3<float>(p[0], p[1], p[2]); }
 template <class T> DEV V3T<T> ld3t(const float *p) { return v3<T>(T(p[0]), T(p[1]), T(p[2])); }     // a model constant, same for every component
 template <class T> DEV V3T<T> splat3(V3 a) { return v3<T>(T(a.x), T(a.y), T(a.z)); }
@@ -158,6 +170,26 @@ template <class T> DEV SVT<T> mul(const Sym6T<T> &A, SVT<T> s) {
     return f;
 }
 template <class T> DEV void add(Sym6T<T> &a, const Sym6T<T> &b) { add(a.AA, b.AA); add(a.AL, b.AL); add(a.LL, b.LL); }
+namespace pk3 {      // (see above) matrix-vector products on the (x, y) + z split: (xx, yy) and (xz, yz) are pairs, xy enters through the swapped vector
+DEV V3 mul(const Sym3 &S, V3 v) {
+    const f2 d = {S.xx, S.yy}, o = {S.xz, S.yz}, vxy = {v.x, v.y}, vyx = {v.y, v.x}, sxy = {S.xy, S.xy}, vz = {v.z, v.z};
+    const f2 r = __builtin_elementwise_fma(d, vxy, __builtin_elementwise_fma(sxy, vyx, o * vz));
+    return v3<float>(r.x, r.y, fmaf(S.xz, v.x, fmaf(S.yz, v.y, S.zz * v.z)));
+}
+DEV V3 mulT(const M3 &A, V3 v) { return fma3(v.x, A.r0, fma3(v.y, A.r1, v.z * A.r2)); }
+DEV SV mul(const Rigid &B, SV v) {
+    SV f;
+    f.a = mul(B.I, v.a) + cross(B.h, v.l);
+    f.l = B.m * v.l - cross(B.h, v.a);
+    return f;
+}
+DEV SV mul(const Sym6 &A, SV s) {
+    SV f;
+    f.a = mul(A.AA, s.a) + ::mul(A.AL, s.l);
+    f.l = mulT(A.AL, s.a) + mul(A.LL, s.l);
+    return f;
+}
+}  // namespace pk3
 template <class T> DEV Sym6T<T> sym6_of(const RigidT<T> &B) {
     Sym6T<T> A;
     const T z = T(0.f);
