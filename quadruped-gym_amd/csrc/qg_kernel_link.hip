@@ -244,10 +244,10 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         wsum *= K.ml;                               // the spare lane is no link (its mass and inertia are zero as well)
         SV fe;
         ContactDampT<float> cd;
-        contact_eval(wsum, s, Ep, pp, nb, vp, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, cd);
+        pk3::contact_eval(wsum, s, Ep, pp, nb, vp, C.contact_k, C.contact_c, C.contact_inv_ramp, C.contact_mu, h, fe, cd);
         f.a = f.a - fe.a;
         f.l = f.l - fe.l;
-        add_contact_damping(A, cd.mc, cd.w, cd.P, nb);
+        pk3::add_contact_damping(A, cd.mc, cd.w, cd.P, nb);
     }
     // FRAME contact: every link lane evaluates one of the FRAME's twelve sample points
     float wsumF = 0.f;
@@ -381,7 +381,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
             b.a = b.a + fe.a;
             b.l = b.l + fe.l;
         }
-        base_solve(Ic0, b, x6);
+        pk3::base_solve(Ic0, b, x6);
     }
     const V3 wdot = v3(x6[0], x6[1], x6[2]);
     const V3 acl = v3(x6[3], x6[4], x6[5]);

@@ -171,12 +171,21 @@ template <class T> DEV SVT<T> mul(const Sym6T<T> &A, SVT<T> s) {
 }
 template <class T> DEV void add(Sym6T<T> &a, const Sym6T<T> &b) { add(a.AA, b.AA); add(a.AL, b.AL); add(a.LL, b.LL); }
 namespace pk3 {      // (see above) matrix-vector products on the (x, y) + z split: (xx, yy) and (xz, yz) are pairs, xy enters through the swapped vector
+// s * (v.y, v.x) + acc in one instruction: the swap of a pair's halves is an op_sel modifier (the compiler folds a broadcast into
+// op_sel, a swap only now and then -- two v_mov otherwise); s rides in the low half of a pair whose high half is never read
+DEV f2 fma_swapped(float s, f2 v, f2 acc) {
+    f2 sp, r;
+    sp.x = s;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(sp), "v"(v), "v"(acc));
+    return r;
+}
 DEV V3 mul(const Sym3 &S, V3 v) {
-    const f2 d = {S.xx, S.yy}, o = {S.xz, S.yz}, vxy = {v.x, v.y}, vyx = {v.y, v.x}, sxy = {S.xy, S.xy}, vz = {v.z, v.z};
-    const f2 r = __builtin_elementwise_fma(d, vxy, __builtin_elementwise_fma(sxy, vyx, o * vz));
+    const f2 d = {S.xx, S.yy}, o = {S.xz, S.yz}, vxy = {v.x, v.y}, vz = {v.z, v.z};
+    const f2 r = __builtin_elementwise_fma(d, vxy, fma_swapped(S.xy, vxy, o * vz));
     return v3<float>(r.x, r.y, fmaf(S.xz, v.x, fmaf(S.yz, v.y, S.zz * v.z)));
 }
 DEV V3 mulT(const M3 &A, V3 v) { return fma3(v.x, A.r0, fma3(v.y, A.r1, v.z * A.r2)); }
+DEV V3 rot(const Fr &E, V3 r) { return fma3(r.x, E.ex, fma3(r.y, E.ey, r.z * E.ez)); }   // local -> working
 DEV SV mul(const Rigid &B, SV v) {
     SV f;
     f.a = mul(B.I, v.a) + cross(B.h, v.l);
@@ -336,35 +345,46 @@ template <class T> DEV void contact_point(V3T<T> r, V3T<T> nl, T zb, T &wsum, V3
 // The implicit (velocity-proportional) part of one aggregated contact: h * (ct * point-mass(P) + (cn - ct) * a a^T), a = [P x n; n],
 // kept as five numbers until the composite inertia it belongs to is assembled.
 template <class T> struct ContactDampT { T mc, w; V3T<T> P; };
-template <class T>
-DEV void contact_eval(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp, float mu, float h,
-                      SVT<T> &f_ext, ContactDampT<T> &cd) {
-    const T zero = T(0.f);
-    auto active = wsum > zero;
-    T W = kc * wsum;
-    T cc = cmax * min_(wsum * inv_ramp, T(1.f));
-    T inv = rcp(sel(active, wsum, T(1.f)));
-    V3T<T> P = p + rot(E, inv * s);         // centre of pressure, FRAME axes about the FRAME origin
-    V3T<T> vP = v.l + cross(v.a, P);
-    T vn = dot(n, vP);
-    V3T<T> vt = vP - vn * n;
-    T Fn0 = W - cc * vn;
-    auto lifted = Fn0 < zero;                // no adhesion: the secant damping coefficient replaces c (vn > 0 here)
-    T Fn = sel(lifted, zero, Fn0);
-    T cn = sel(lifted, W * rcp(vn), cc);
-    T speed = sqrt_(dot(vt, vt));
-    auto sliding = cc * speed > mu * Fn;     // Coulomb limit (speed > 0 here)
-    T ct = sel(sliding, mu * Fn * rcp(speed), cc);
-    Fn = sel(active, Fn, zero);
-    cn = sel(active, cn, zero);
-    ct = sel(active, ct, zero);
-    V3T<T> F = Fn * n - ct * vt;
-    f_ext.a = cross(P, F);
-    f_ext.l = F;
-    cd.mc = h * ct;
-    cd.w = h * (cn - ct);
-    cd.P = P;
+#define QG_TEMPLATE_T template <class T>
+#include "qg_contact_eval.inc"
+#undef QG_TEMPLATE_T
+namespace pk3 {
+typedef float T;
+#define QG_TEMPLATE_T
+#include "qg_contact_eval.inc"
+#undef QG_TEMPLATE_T
+// add_contact_damping on the pairs the packed code keeps a symmetric block in: (xx, yy), (xz, yz) and the (x, y) halves of AL's rows
+DEV void add_contact_damping(Sym6 &A, float m, float w, V3 r, V3 n) {
+    const float rr = dot(r, r);
+    const V3 h = m * r;
+    const f2 hxy = {h.x, h.y}, rxy = {r.x, r.y}, nxy = {n.x, n.y};
+    const float mrr = m * rr;
+    // point mass at r: m (r.r I - r r^T), [h]x, m I
+    const f2 aad = f2{A.AA.xx, A.AA.yy} + __builtin_elementwise_fma(-hxy, rxy, f2{mrr, mrr});
+    const f2 aao = __builtin_elementwise_fma(-hxy, f2{r.z, r.z}, f2{A.AA.xz, A.AA.yz});
+    A.AA.zz += fmaf(-h.z, r.z, mrr);
+    A.AA.xy = fmaf(-h.x, r.y, A.AA.xy);
+    A.AL.r0.y -= h.z; A.AL.r0.z += h.y;
+    A.AL.r1.x += h.z; A.AL.r1.z -= h.x;
+    const f2 r2xy = f2{A.AL.r2.x, A.AL.r2.y} + f2{-h.y, h.x};
+    const f2 lld = f2{A.LL.xx, A.LL.yy} + f2{m, m};
+    A.LL.zz += m;
+    // w a a^T, a = [r x n; n]
+    const V3 ra = cross(r, n), wra = w * ra, wn = w * n;
+    const f2 raxy = {ra.x, ra.y}, wraxy = {wra.x, wra.y}, wnxy = {wn.x, wn.y};
+    const f2 aad2 = __builtin_elementwise_fma(wraxy, raxy, aad);
+    const f2 aao2 = __builtin_elementwise_fma(wraxy, f2{ra.z, ra.z}, aao);
+    A.AA.xx = aad2.x; A.AA.yy = aad2.y; A.AA.xz = aao2.x; A.AA.yz = aao2.y;
+    A.AA.xy = fmaf(wra.x, ra.y, A.AA.xy); A.AA.zz = fmaf(wra.z, ra.z, A.AA.zz);
+    A.AL.r0 = fma3(wra.x, n, A.AL.r0);
+    A.AL.r1 = fma3(wra.y, n, A.AL.r1);
+    A.AL.r2 = fma3(wra.z, n, v3<float>(r2xy.x, r2xy.y, A.AL.r2.z));
+    const f2 lld2 = __builtin_elementwise_fma(wnxy, nxy, lld);
+    const f2 llo = __builtin_elementwise_fma(wnxy, f2{n.z, n.z}, f2{A.LL.xz, A.LL.yz});
+    A.LL.xx = lld2.x; A.LL.yy = lld2.y; A.LL.xz = llo.x; A.LL.yz = llo.y;
+    A.LL.xy = fmaf(wn.x, n.y, A.LL.xy); A.LL.zz = fmaf(wn.z, n.z, A.LL.zz);
 }
+}  // namespace pk3
 template <class T>
 DEV void contact_finish(T wsum, V3T<T> s, const FrT<T> &E, V3T<T> p, V3T<T> n, SVT<T> v, float kc, float cmax, float inv_ramp, float mu, float h,
                         SVT<T> &f_ext, Sym6T<T> &A) {
@@ -736,6 +756,69 @@ DEV void base_solve(const Sym6 &Ic0, SV rhs, float x6[6]) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) x6[i] = b[i];
 }
+
+namespace pk3 {
+// The same solve with the ROWS taken in pairs (0,1) (2,3) (4,5) as packed FP32, for the kernel that is alone on its SIMD: right-looking
+// LDL^T (column j scaled by 1/d_j, then the trailing columns k > j updated with u_k = the unscaled A[k][j]), forward substitution
+// column by column, backward substitution plain -- 64 instructions + 6 reciprocals against 95.  A pair is formed only of two entries that are both
+// in range; every entry belongs to one pair, so no copies.  (The sums run in another order than base_solve's left-looking loops: the
+// two agree to rounding, not to the bit.)
+DEV void base_solve(const Sym6 &Ic0, SV rhs, float x6[6]) {
+    float A[6][6];
+    A[0][0] = Ic0.AA.xx; A[1][1] = Ic0.AA.yy; A[2][2] = Ic0.AA.zz;
+    A[1][0] = Ic0.AA.xy; A[2][0] = Ic0.AA.xz; A[2][1] = Ic0.AA.yz;
+    A[3][0] = Ic0.AL.r0.x; A[4][0] = Ic0.AL.r0.y; A[5][0] = Ic0.AL.r0.z;
+    A[3][1] = Ic0.AL.r1.x; A[4][1] = Ic0.AL.r1.y; A[5][1] = Ic0.AL.r1.z;
+    A[3][2] = Ic0.AL.r2.x; A[4][2] = Ic0.AL.r2.y; A[5][2] = Ic0.AL.r2.z;
+    A[3][3] = Ic0.LL.xx; A[4][4] = Ic0.LL.yy; A[5][5] = Ic0.LL.zz;
+    A[4][3] = Ic0.LL.xy; A[5][3] = Ic0.LL.xz; A[5][4] = Ic0.LL.yz;
+    float b[6] = {rhs.a.x, rhs.a.y, rhs.a.z, rhs.l.x, rhs.l.y, rhs.l.z};
+    float idg[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        idg[j] = rcp(A[j][j]);
+        float l[6];
+        const f2 id2 = {idg[j], idg[j]};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {                      // L[i][j] = A[i][j] / d_j, rows i > j
+            const int i = 2 * q;
+            if (i > j) { const f2 t = f2{A[i][j], A[i + 1][j]} * id2; l[i] = t.x; l[i + 1] = t.y; }
+            else if (i + 1 > j) l[i + 1] = A[i + 1][j] * idg[j];
+        }
+#pragma unroll
+        for (int k = j + 1; k < 6; ++k) {                  // A[i][k] -= L[i][j] * A[k][j], rows i >= k
+            const f2 nu = {-A[k][j], -A[k][j]};
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i = 2 * q;
+                if (i >= k) { const f2 t = __builtin_elementwise_fma(f2{l[i], l[i + 1]}, nu, f2{A[i][k], A[i + 1][k]}); A[i][k] = t.x; A[i + 1][k] = t.y; }
+                else if (i + 1 >= k) A[i + 1][k] = fmaf(l[i + 1], nu.x, A[i + 1][k]);
+            }
+        }
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) A[i][j] = l[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {                          // forward: b[i] -= L[i][j] * b[j], rows i > j
+        const f2 nb = {-b[j], -b[j]};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int i = 2 * q;
+            if (i > j) { const f2 t = __builtin_elementwise_fma(f2{A[i][j], A[i + 1][j]}, nb, f2{b[i], b[i + 1]}); b[i] = t.x; b[i + 1] = t.y; }
+            else if (i + 1 > j) b[i + 1] = fmaf(A[i + 1][j], nb.x, b[i + 1]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const f2 t = f2{b[2 * q], b[2 * q + 1]} * f2{idg[2 * q], idg[2 * q + 1]}; b[2 * q] = t.x; b[2 * q + 1] = t.y; }
+#pragma unroll
+    for (int i = 4; i >= 0; --i) {                         // backward: plain multiply-adds (row j of L^T is a COLUMN of the pairs above)
+#pragma unroll
+        for (int t = i + 1; t < 6; ++t) b[i] = fmaf(-A[t][i], b[t], b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x6[i] = b[i];
+}
+}  // namespace pk3
 
 // semi-implicit integration of the base: velocity, then position / quaternion with the NEW velocity
 // RSQ: one v_rsq_f32 (1 ulp) for the final normalisation instead of v_sqrt_f32 + v_rcp_f32
