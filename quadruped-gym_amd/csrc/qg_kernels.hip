@@ -1230,7 +1230,8 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
                 b.l = b.l + fe.l;
             }
         }
-        base_solve(Ic0, b, x6);
+        if constexpr (BAKED) pk3::base_solve(Ic0, b, x6);      // packed row pairs: fewer instructions for a wave alone on its SIMD, as many
+        else base_solve(Ic0, b, x6);                            // issue cycles at two waves per SIMD; the generic robot's register budget has no room for the pairs
     }
     V3 wdot = v3(x6[0], x6[1], x6[2]);
     V3 acl = v3(x6[3], x6[4], x6[5]);
@@ -1788,7 +1789,8 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
                 b.l = b.l + fe.l;
             }
         }
-        base_solve(Ic0, b, x6);
+        base_solve(Ic0, b, x6);     // (pk3::base_solve: 36 instructions fewer and 2.7 % SLOWER here, 24.96 -> 25.64 us at 32 768 envs: the solve sits on
+                                     // this kernel's dependent tail, and a dependent packed instruction costs a lone wave ~1.5 plain ones)
     }
     V3 wdot = v3<float>(x6[0], x6[1], x6[2]);
     V3 acl = v3<float>(x6[3], x6[4], x6[5]);
