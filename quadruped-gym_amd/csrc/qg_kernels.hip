@@ -1790,7 +1790,8 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
             }
         }
         base_solve(Ic0, b, x6);     // (pk3::base_solve: 36 instructions fewer and 2.7 % SLOWER here, 24.96 -> 25.64 us at 32 768 envs: the solve sits on
-                                     // this kernel's dependent tail, and a dependent packed instruction costs a lone wave ~1.5 plain ones)
+                                     // this kernel's dependent tail, and a dependent packed instruction costs a lone wave ~1.5 plain ones; the same right-looking
+                                     // order in plain FP32, 15 instructions fewer: no difference, 24.9-25.1 us either way)
     }
     V3 wdot = v3<float>(x6[0], x6[1], x6[2]);
     V3 acl = v3<float>(x6[3], x6[4], x6[5]);
