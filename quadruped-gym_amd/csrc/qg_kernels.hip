@@ -1703,33 +1703,18 @@ DEV float hsum(f2 v) {
 }
 DEV V3 hsum(V3T<f2> v) { return v3<float>(hsum(v.x), hsum(v.y), hsum(v.z)); }
 DEV V3 pair_sum(V3 a) { return v3<float>(pair_sum(a.x), pair_sum(a.y), pair_sum(a.z)); }
-// The 33 sums of the substep (composite inertia 21, force 6, F u 6) over the two legs of the lane and the two lanes of the env.  The lane-pair
-// adds are written as v_add_f32_dpp in assembly blocks: left to the compiler they stay mov_dpp + add with a hazard s_nop in front of
-// almost every one (33 + 25 issue slots per substep; its DPP combiner fuses a move into its add only when the two end up adjacent).
-// Hazard: a DPP read needs 2 wait states behind a VALU write of the same register, and the recogniser does not look into assembly:
-// s_nop 1 at both ends of a block; inside it no instruction reads what another one wrote.
-#define QG_PS(i) "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-DEV void pair_sum6(float &a, float &b, float &c, float &d, float &e, float &f) {
-    asm("s_nop 1\n\t" QG_PS(0) QG_PS(1) QG_PS(2) QG_PS(3) QG_PS(4) QG_PS(5) "s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+DEV Sym3 hpsum(const Sym3T<f2> &a) {
+    Sym3 r = {pair_sum(hsum(a.xx)), pair_sum(hsum(a.yy)), pair_sum(hsum(a.zz)), pair_sum(hsum(a.xy)), pair_sum(hsum(a.xz)), pair_sum(hsum(a.yz))};
+    return r;
 }
-DEV void pair_sum9(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &h, float &i) {
-    asm("s_nop 1\n\t" QG_PS(0) QG_PS(1) QG_PS(2) QG_PS(3) QG_PS(4) QG_PS(5) QG_PS(6) QG_PS(7) QG_PS(8) "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
+DEV Sym6 hpsum(const Sym6T<f2> &a) {
+    Sym6 r;
+    r.AA = hpsum(a.AA);
+    r.LL = hpsum(a.LL);
+    r.AL.r0 = pair_sum(hsum(a.AL.r0)); r.AL.r1 = pair_sum(hsum(a.AL.r1)); r.AL.r2 = pair_sum(hsum(a.AL.r2));
+    return r;
 }
-DEV void pair_sum12(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &h, float &i, float &j, float &k, float &l) {
-    asm("s_nop 1\n\t" QG_PS(0) QG_PS(1) QG_PS(2) QG_PS(3) QG_PS(4) QG_PS(5) QG_PS(6) QG_PS(7) QG_PS(8) QG_PS(9) QG_PS(10) QG_PS(11) "s_nop 1"
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i), "+v"(j), "+v"(k), "+v"(l));
-}
-#undef QG_PS
-DEV Sym3 hsum(const Sym3T<f2> &a) { Sym3 r = {hsum(a.xx), hsum(a.yy), hsum(a.zz), hsum(a.xy), hsum(a.xz), hsum(a.yz)}; return r; }
-DEV void hpsum33(const Sym6T<f2> &Ic2, const SVT<f2> &fc2, const SVT<f2> &Fu2, Sym6 &Ic, SV &fc, SV &Fu) {
-    Ic.AA = hsum(Ic2.AA); Ic.LL = hsum(Ic2.LL);
-    Ic.AL.r0 = hsum(Ic2.AL.r0); Ic.AL.r1 = hsum(Ic2.AL.r1); Ic.AL.r2 = hsum(Ic2.AL.r2);
-    fc.a = hsum(fc2.a); fc.l = hsum(fc2.l); Fu.a = hsum(Fu2.a); Fu.l = hsum(Fu2.l);
-    pair_sum12(Ic.AA.xx, Ic.AA.yy, Ic.AA.zz, Ic.AA.xy, Ic.AA.xz, Ic.AA.yz, Ic.LL.xx, Ic.LL.yy, Ic.LL.zz, Ic.LL.xy, Ic.LL.xz, Ic.LL.yz);
-    pair_sum9(Ic.AL.r0.x, Ic.AL.r0.y, Ic.AL.r0.z, Ic.AL.r1.x, Ic.AL.r1.y, Ic.AL.r1.z, Ic.AL.r2.x, Ic.AL.r2.y, Ic.AL.r2.z);
-    pair_sum12(fc.a.x, fc.a.y, fc.a.z, fc.l.x, fc.l.y, fc.l.z, Fu.a.x, Fu.a.y, Fu.a.z, Fu.l.x, Fu.l.y, Fu.l.z);
-}
+DEV SV hpsum(const SVT<f2> &v) { SV r = {pair_sum(hsum(v.a)), pair_sum(hsum(v.l))}; return r; }
 
 struct LegPair { f2 q[3], qd[3], act[3], u[3], sc[6]; };   // sc: sin, cos of (q[i] - ref_i) of both legs, advanced with the hinges
 
@@ -1770,7 +1755,9 @@ DEV void substep_pair(const KModel &C, f2 cm, f2 sm, BaseState &B, LegPair &L, b
         // (33 v_mov_b32_dpp per substep: the compiler fuses a move into its add only when the two are close, see substep_quad), but
         // with the sums right in front of the 6x6 solve the lone wave of this kernel ran 2.6 % slower at 32 768 and at 262 144 envs
         // (same-box A/B, round 3: 25.0 -> 25.65 us; the dependent chain sum -> assemble -> solve has nothing to overlap with there)
-        hpsum33(Ic2, fc2, Fu2, Ic, fc, Fu);
+        Ic = hpsum(Ic2);
+        fc = hpsum(fc2);
+        Fu = hpsum(Fu2);
     }
     float x6[6];
     {
