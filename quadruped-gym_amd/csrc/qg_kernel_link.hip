@@ -401,7 +401,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         hinge_advance(h * J.qd, J.sn, J.cs);
         J.act = fmaf(J.u - J.act, K.act_decay, J.act);
     }
-    base_integrate<true>(bc, h, wdot, acl, B);
+    pk3::base_integrate_unit(bc, h, wdot, acl, B);
 }
 
 // Workgroups of four waves (one per SIMD of a CU): a grid of 1024 one-wave workgroups measured 1.65 us more fixed time per launch

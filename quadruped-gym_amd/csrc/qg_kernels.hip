@@ -174,8 +174,9 @@ namespace pk3 {      // (see above) matrix-vector products on the (x, y) + z spl
 // s * (v.y, v.x) + acc in one instruction: the swap of a pair's halves is an op_sel modifier (the compiler folds a broadcast into
 // op_sel, a swap only now and then -- two v_mov otherwise); s rides in the low half of a pair whose high half is never read
 DEV f2 fma_swapped(float s, f2 v, f2 acc) {
-    f2 sp, r;
-    sp.x = s;
+    f2 sp = __builtin_nondeterministic_value(sp);              // (s, don't care): only the low half is selected below; the builtin
+    sp.x = s;                                                  // gives the other half SOME value without an instruction (frozen poison)
+    f2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(sp), "v"(v), "v"(acc));
     return r;
 }
@@ -852,6 +853,45 @@ DEV void base_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B
     float inv = RSQ ? __builtin_amdgcn_rsqf(n2) : rcp(__builtin_amdgcn_sqrtf(n2));
     B.qw = nw * inv; B.qx = nx * inv; B.qy = ny * inv; B.qz = nz * inv;
 }
+
+namespace pk3 {
+// d = s * (a with the modifiers MODS) + c, s riding in the low half of a pair (see fma_swapped): one packed multiply-add of the
+// quaternion product below, whose swaps and signs are all operand modifiers
+#define QG_PKQ(dst, s, a, c, MODS) do { f2 sp_ = __builtin_nondeterministic_value(sp_); sp_.x = (s); \
+        asm("v_pk_fma_f32 %0, %1, %2, %3 " MODS : "=v"(dst) : "v"(sp_), "v"(a), "v"(c)); } while (0)
+#define QG_PKQM(dst, s, a, MODS) do { f2 sp_ = __builtin_nondeterministic_value(sp_); sp_.x = (s); \
+        asm("v_pk_mul_f32 %0, %1, %2 " MODS : "=v"(dst) : "v"(sp_), "v"(a)); } while (0)
+// base_integrate<true> with the 3-vector updates and the quaternion product q * (cw, dv) as packed FP32 on P1 = (cw, dv.x), P2 = (dv.y, dv.z):
+//   (nw, nx) = w (cw, dv.x) + x (-dv.x, cw) + y (-dv.y, dv.z) + z (-dv.z, -dv.y);   (ny, nz) = w (dv.y, dv.z) + x (-dv.z, dv.y) + y (cw, -dv.x) + z (dv.x, cw)
+DEV void base_integrate_unit(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B) {
+    V3 aw = fma3(acl.x, c.cx, fma3(acl.y, c.cy, acl.z * c.cz));
+    B.vw = fma3(h, aw, B.vw);
+    B.wb = fma3(h, wdot, B.wb);
+    B.pw = fma3(h, B.vw, B.pw);
+    const float hh = 0.5f * h;
+    const float x2 = hh * hh * dot(B.wb, B.wb);
+    const float sc = hh * fmaf(x2, fmaf(x2, 1.f / 120.f, -1.f / 6.f), 1.f);
+    const float cw = fmaf(x2, fmaf(x2, 1.f / 24.f, -0.5f), 1.f);
+    const V3 dv = sc * B.wb;
+    const f2 P1 = {cw, dv.x}, P2 = {dv.y, dv.z};
+    f2 a, b;
+    QG_PKQM(a, c.z, P2, "op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]");            // z (-dv.z, -dv.y)
+    QG_PKQ(a, c.y, P2, a, "op_sel_hi:[0,1,1] neg_lo:[0,1,0]");                                // + y (-dv.y, dv.z)
+    QG_PKQ(a, c.x, P1, a, "op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]");                 // + x (-dv.x, cw)
+    QG_PKQ(a, c.w, P1, a, "op_sel_hi:[0,1,1]");                                               // + w (cw, dv.x)
+    QG_PKQM(b, c.z, P1, "op_sel:[0,1] op_sel_hi:[0,0]");                                      // z (dv.x, cw)
+    QG_PKQ(b, c.y, P1, b, "op_sel_hi:[0,1,1] neg_hi:[0,1,0]");                                // + y (cw, -dv.x)
+    QG_PKQ(b, c.x, P2, b, "op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]");                 // + x (-dv.z, dv.y)
+    QG_PKQ(b, c.w, P2, b, "op_sel_hi:[0,1,1]");                                               // + w (dv.y, dv.z)
+    const f2 n2 = __builtin_elementwise_fma(b, b, a * a);
+    const float inv = __builtin_amdgcn_rsqf(n2.x + n2.y);
+    const f2 i2 = {inv, inv};
+    a = a * i2; b = b * i2;
+    B.qw = a.x; B.qx = a.y; B.qy = b.x; B.qz = b.y;
+}
+#undef QG_PKQ
+#undef QG_PKQM
+}  // namespace pk3
 
 // ------------------------------------------------------------------------------------------
 // per-lane scratch columns in LDS: slot s of lane l lives at lds[s * 64 + l] (conflict-free)
