@@ -136,7 +136,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
                       bool want_sensors, float *__restrict__ row, int kleg, float &zaxis_z) {
     using namespace pk3;
     const float h = C.h;
-    const BaseCtx bc = base_prelude<true>(C, B);     // the quaternion is of unit length here (normalised at load, then by base_integrate)
+    const BaseCtx bc = pk3::base_prelude_unit(C, B); // the quaternion is of unit length here (normalised at load, then by base_integrate)
     const V3 nb = bc.n;
     if (want_sensors) {              // the step's sensordata describes the state at the start of its last substep
         zaxis_z = bc.cz.z;

@@ -174,9 +174,9 @@ namespace pk3 {      // (see above) matrix-vector products on the (x, y) + z spl
 // s * (v.y, v.x) + acc in one instruction: the swap of a pair's halves is an op_sel modifier (the compiler folds a broadcast into
 // op_sel, a swap only now and then -- two v_mov otherwise); s rides in the low half of a pair whose high half is never read
 DEV f2 fma_swapped(float s, f2 v, f2 acc) {
-    f2 sp = __builtin_nondeterministic_value(sp);              // (s, don't care): only the low half is selected below; the builtin
-    sp.x = s;                                                  // gives the other half SOME value without an instruction (frozen poison)
-    f2 r;
+    f2 sp, r;                                                  // (s, don't care): only the low half is selected below.  Left
+    sp.x = s;                                                  // unset on purpose: __builtin_nondeterministic_value (frozen poison)
+                                                               // becomes a v_mov from a zero register per call
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(sp), "v"(v), "v"(acc));
     return r;
 }
@@ -855,14 +855,49 @@ DEV void base_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B
 }
 
 namespace pk3 {
-// d = s * (a with the modifiers MODS) + c, s riding in the low half of a pair (see fma_swapped): one packed multiply-add of the
-// quaternion product below, whose swaps and signs are all operand modifiers
-#define QG_PKQ(dst, s, a, c, MODS) do { f2 sp_ = __builtin_nondeterministic_value(sp_); sp_.x = (s); \
-        asm("v_pk_fma_f32 %0, %1, %2, %3 " MODS : "=v"(dst) : "v"(sp_), "v"(a), "v"(c)); } while (0)
-#define QG_PKQM(dst, s, a, MODS) do { f2 sp_ = __builtin_nondeterministic_value(sp_); sp_.x = (s); \
-        asm("v_pk_mul_f32 %0, %1, %2 " MODS : "=v"(dst) : "v"(sp_), "v"(a)); } while (0)
-// base_integrate<true> with the 3-vector updates and the quaternion product q * (cw, dv) as packed FP32 on P1 = (cw, dv.x), P2 = (dv.y, dv.z):
-//   (nw, nx) = w (cw, dv.x) + x (-dv.x, cw) + y (-dv.y, dv.z) + z (-dv.z, -dv.y);   (ny, nz) = w (dv.y, dv.z) + x (-dv.z, dv.y) + y (cw, -dv.x) + z (dv.x, cw)
+// One packed multiply(-add) whose swaps, broadcasts and signs are all operand modifiers (the compiler folds a broadcast into op_sel,
+// a swap or a sign only now and then -- v_mov / v_xor otherwise).  Every operand is a pair that exists anyway: the quaternion is held
+// as W = (w, z), X = (x, y) from substep to substep, so a broadcast of one component is an op_sel of its pair and nothing rides in a
+// pair with a don't-care half (frozen poison costs a v_mov from a zero register per pair: measured, 8 in the loop).
+#define QG_PKFMA(dst, a, b, c, MODS) asm("v_pk_fma_f32 %0, %1, %2, %3 " MODS : "=v"(dst) : "v"(a), "v"(b), "v"(c))
+#define QG_PKMUL(dst, a, b, MODS) asm("v_pk_mul_f32 %0, %1, %2 " MODS : "=v"(dst) : "v"(a), "v"(b))
+// base_prelude<true> with the rotation matrix of the UNIT quaternion in nine instructions: with W2 = 2 W, X2 = 2 X and k = 2ww - 1
+//   A = (k, 2wz);  (cx.x, cx.y) = 2x (x, y) + A;  (cy.x, cy.y) = 2y (x, y) + (-A.hi, A.lo);  T = 2w (y, x)
+//   (cz.x, cz.y) = (2x, 2y) z + (T.lo, -T.hi);  (cx.z, cy.z) = (2x, 2y) z + (-T.lo, T.hi);  cz.z = 2zz + k
+// -- the diagonal as 2(ww + qq) - 1 instead of 1 - 2(rr + ss): the same number for a unit quaternion, other rounding.  The pairs are
+// the (x, y) halves of the packed 3-vector operators; (cx.z, cy.z) is the (x, y) half of the world's up axis n.
+// a value the optimiser cannot see through (no instruction): keeps the loads of two ADJACENT fields of a struct from being merged
+// into one vector load -- here that load would straddle the (qw, qx) pair other code writes as a vector, the struct could no longer
+// be split into registers and landed in LDS (.amdhsa_group_segment_fixed_size 2 240 -> 5 312)
+DEV float opaque(float v) { asm("" : "+v"(v)); return v; }
+DEV BaseCtx base_prelude_unit(const KModel &C, const BaseState &B) {
+    BaseCtx c;                                           // (c.w .. c.z stay unset: base_integrate_unit reads the quaternion from B)
+    const f2 W = {B.qw, B.qz}, X = {opaque(B.qx), opaque(B.qy)};
+    const f2 W2 = W + W, X2 = X + X;
+    const f2 m10 = {-1.f, 0.f};
+    f2 A, cxp, cyp, T, czp, np;
+    QG_PKFMA(A, W2, W, m10, "op_sel_hi:[0,1,1]");                                            // (2ww - 1, 2wz)
+    QG_PKFMA(cxp, X2, X, A, "op_sel_hi:[0,1,1]");                                            // 2x (x, y) + A
+    QG_PKFMA(cyp, X2, X, A, "op_sel:[1,0,1] op_sel_hi:[1,1,0] neg_lo:[0,0,1]");              // 2y (x, y) + (-A.hi, A.lo)
+    QG_PKMUL(T, W2, X, "op_sel:[0,1] op_sel_hi:[0,0]");                                      // 2w (y, x)
+    QG_PKFMA(czp, X2, W, T, "op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_hi:[0,0,1]");              // (2x, 2y) z + (T.lo, -T.hi)
+    QG_PKFMA(np, X2, W, T, "op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,0,1]");               // (2x, 2y) z + (-T.lo, T.hi)
+    c.cx = v3(cxp.x, cxp.y, np.x);
+    c.cy = v3(cyp.x, cyp.y, np.y);
+    c.cz = v3(czp.x, czp.y, fmaf(W2.y, W.y, A.x));
+    c.n = v3(c.cx.z, c.cy.z, c.cz.z);
+    V3 gw = ld3(C.g);
+    c.gb = v3(dot(c.cx, gw), dot(c.cy, gw), dot(c.cz, gw));
+    c.vb = v3(dot(c.cx, B.vw), dot(c.cy, B.vw), dot(c.cz, B.vw));
+    c.V0.a = B.wb; c.V0.l = c.vb;
+    c.A0.a = v3(0.f, 0.f, 0.f);
+    c.A0.l = v3(0.f, 0.f, 0.f) - cross(B.wb, c.vb) - c.gb;
+    return c;
+}
+// base_integrate<true> with the 3-vector updates and the quaternion product q * (cw, dv) as eight packed multiply-adds on
+// DW = (cw, dv.z), DX = (dv.x, dv.y) -- dv's own (x, y) pair; cw and dv.z are plain producers that write into their halves:
+//   (nw, nz) = w (cw, dz) + x (-dx, dy) + y (-dy, -dx) + z (-dz, cw);   (nx, ny) = w (dx, dy) + x (cw, -dz) + y (dz, cw) + z (-dy, dx)
+// (each component sums its four products in the order z, y, x, w)
 DEV void base_integrate_unit(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B) {
     V3 aw = fma3(acl.x, c.cx, fma3(acl.y, c.cy, acl.z * c.cz));
     B.vw = fma3(h, aw, B.vw);
@@ -873,24 +908,25 @@ DEV void base_integrate_unit(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseSta
     const float sc = hh * fmaf(x2, fmaf(x2, 1.f / 120.f, -1.f / 6.f), 1.f);
     const float cw = fmaf(x2, fmaf(x2, 1.f / 24.f, -0.5f), 1.f);
     const V3 dv = sc * B.wb;
-    const f2 P1 = {cw, dv.x}, P2 = {dv.y, dv.z};
+    const f2 W = {B.qw, B.qz}, X = {opaque(B.qx), opaque(B.qy)};
+    const f2 DW = {cw, dv.z}, DX = {dv.x, dv.y};
     f2 a, b;
-    QG_PKQM(a, c.z, P2, "op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[0,1]");            // z (-dv.z, -dv.y)
-    QG_PKQ(a, c.y, P2, a, "op_sel_hi:[0,1,1] neg_lo:[0,1,0]");                                // + y (-dv.y, dv.z)
-    QG_PKQ(a, c.x, P1, a, "op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]");                 // + x (-dv.x, cw)
-    QG_PKQ(a, c.w, P1, a, "op_sel_hi:[0,1,1]");                                               // + w (cw, dv.x)
-    QG_PKQM(b, c.z, P1, "op_sel:[0,1] op_sel_hi:[0,0]");                                      // z (dv.x, cw)
-    QG_PKQ(b, c.y, P1, b, "op_sel_hi:[0,1,1] neg_hi:[0,1,0]");                                // + y (cw, -dv.x)
-    QG_PKQ(b, c.x, P2, b, "op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]");                 // + x (-dv.z, dv.y)
-    QG_PKQ(b, c.w, P2, b, "op_sel_hi:[0,1,1]");                                               // + w (dv.y, dv.z)
+    QG_PKMUL(a, W, DW, "op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]");                                  // z (-dz, cw)
+    QG_PKFMA(a, X, DX, a, "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]");          // + y (-dy, -dx)
+    QG_PKFMA(a, X, DX, a, "op_sel_hi:[0,1,1] neg_lo:[0,1,0]");                                        // + x (-dx, dy)
+    QG_PKFMA(a, W, DW, a, "op_sel_hi:[0,1,1]");                                                       // + w (cw, dz)
+    QG_PKMUL(b, W, DX, "op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]");                                  // z (-dy, dx)
+    QG_PKFMA(b, X, DW, b, "op_sel:[1,1,0] op_sel_hi:[1,0,1]");                                        // + y (dz, cw)
+    QG_PKFMA(b, X, DW, b, "op_sel_hi:[0,1,1] neg_hi:[0,1,0]");                                        // + x (cw, -dz)
+    QG_PKFMA(b, W, DX, b, "op_sel_hi:[0,1,1]");                                                       // + w (dx, dy)
     const f2 n2 = __builtin_elementwise_fma(b, b, a * a);
     const float inv = __builtin_amdgcn_rsqf(n2.x + n2.y);
     const f2 i2 = {inv, inv};
     a = a * i2; b = b * i2;
-    B.qw = a.x; B.qx = a.y; B.qy = b.x; B.qz = b.y;
+    B.qw = a.x; B.qz = a.y; B.qx = b.x; B.qy = b.y;
 }
-#undef QG_PKQ
-#undef QG_PKQM
+#undef QG_PKFMA
+#undef QG_PKMUL
 }  // namespace pk3
 
 // ------------------------------------------------------------------------------------------
