@@ -188,7 +188,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         vp.l = leg_prefix(qdm * So.l) + bc.V0.l;
         // a = a_parent + (v x S) qd, v the link's own velocity
         const V3 ca = qdm * cross(vp.a, So.a);
-        const V3 cl = qdm * (cross(vp.a, So.l) + cross(vp.l, So.a));
+        const V3 cl = qdm * cross_add(vp.l, So.a, cross(vp.a, So.l));
         ap.a = leg_prefix(ca) + bc.A0.a;
         ap.l = leg_prefix(cl) + bc.A0.l;
     }
@@ -216,8 +216,8 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     SV f;
     {
         SV Iv = mul(Bi, vp), Ia = mul(Bi, ap);
-        f.a = Ia.a + cross(vp.a, Iv.a) + cross(vp.l, Iv.l);
-        f.l = Ia.l + cross(vp.a, Iv.l);
+        f.a = cross_add(vp.l, Iv.l, cross_add(vp.a, Iv.a, Ia.a));
+        f.l = cross_add(vp.a, Iv.l, Ia.l);
     }
     Sym6 A = sym6_of(Bi);
     {

@@ -114,6 +114,29 @@ DEV V3 fma3(float s, V3 a, V3 b) { f2 A = {a.x, a.y}, Bv = {b.x, b.y}, S = {s, s
 DEV V3 operator+(V3 a, V3 b) { f2 A = {a.x, a.y}, Bv = {b.x, b.y}; f2 r = A + Bv; return v3<float>(r.x, r.y, a.z + b.z); }
 DEV V3 operator-(V3 a, V3 b) { f2 A = {a.x, a.y}, Bv = {b.x, b.y}; f2 r = A - Bv; return v3<float>(r.x, r.y, a.z - b.z); }
 DEV V3 operator*(float s, V3 a) { f2 A = {a.x, a.y}, S = {s, s}; f2 r = S * A; return v3<float>(r.x, r.y, s * a.z); }
+// a x b with its (x, y) half as two packed instructions, (a.y b.z - a.z b.y, a.z b.x - a.x b.z) = a.z (-b.y, b.x) + (a.y, -a.x) b.z:
+// the swaps and signs are operand modifiers (written out: the compiler folds a swap only now and then); a.z and b.z ride in the
+// low half of a pair whose other half is never read and is left unset on purpose (any initialiser is a v_mov).  Four instructions
+// for six; the product a.z b is rounded before the multiply-add (the compiler's own contraction rounds one of the two products too).
+// (an operand with a component known at compile time -- the compiled-in robot's mount axes -- takes the plain form, which folds)
+DEV bool has_literal(V3 a) { return __builtin_constant_p(a.x) || __builtin_constant_p(a.y) || __builtin_constant_p(a.z); }
+DEV V3 cross(V3 a, V3 b) {
+    if (has_literal(a) || has_literal(b)) return ::cross<float>(a, b);
+    f2 A = {a.x, a.y}, Bv = {b.x, b.y}, az, bz, m, r;
+    az.x = a.z; bz.x = b.z;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(m) : "v"(az), "v"(Bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(A), "v"(bz), "v"(m));
+    return v3<float>(r.x, r.y, a.x * b.y - a.y * b.x);
+}
+// acc + a x b: the same two packed instructions with the sum as their addend (acc - a x b is cross_add(b, a, acc))
+DEV V3 cross_add(V3 a, V3 b, V3 acc) {
+    if (has_literal(a) || has_literal(b)) return ::operator+<float>(acc, ::cross<float>(a, b));
+    f2 A = {a.x, a.y}, Bv = {b.x, b.y}, C2 = {acc.x, acc.y}, az, bz, m, r;
+    az.x = a.z; bz.x = b.z;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(m) : "v"(az), "v"(Bv), "v"(C2));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(A), "v"(bz), "v"(m));
+    return v3<float>(r.x, r.y, fmaf(a.x, b.y, fmaf(-a.y, b.x, acc.z)));
+}
 }  // namespace pk3
 DEV V3 ld3(const float *p) { return v3<float>(p[0], p[1], p[2]); }
 template <class T> DEV V3T<T> ld3t(const float *p) { return v3<T>(T(p[0]), T(p[1]), T(p[2])); }     // a model constant, same for every component
@@ -189,8 +212,8 @@ DEV V3 mulT(const M3 &A, V3 v) { return fma3(v.x, A.r0, fma3(v.y, A.r1, v.z * A.
 DEV V3 rot(const Fr &E, V3 r) { return fma3(r.x, E.ex, fma3(r.y, E.ey, r.z * E.ez)); }   // local -> working
 DEV SV mul(const Rigid &B, SV v) {
     SV f;
-    f.a = mul(B.I, v.a) + cross(B.h, v.l);
-    f.l = B.m * v.l - cross(B.h, v.a);
+    f.a = cross_add(B.h, v.l, mul(B.I, v.a));
+    f.l = cross_add(v.a, B.h, B.m * v.l);               // m v - h x w
     return f;
 }
 DEV SV mul(const Sym6 &A, SV s) {
@@ -891,7 +914,7 @@ DEV BaseCtx base_prelude_unit(const KModel &C, const BaseState &B) {
     c.vb = v3(dot(c.cx, B.vw), dot(c.cy, B.vw), dot(c.cz, B.vw));
     c.V0.a = B.wb; c.V0.l = c.vb;
     c.A0.a = v3(0.f, 0.f, 0.f);
-    c.A0.l = v3(0.f, 0.f, 0.f) - cross(B.wb, c.vb) - c.gb;
+    c.A0.l = cross_add(c.vb, B.wb, v3(-c.gb.x, -c.gb.y, -c.gb.z));        // -(w x v) - g
     return c;
 }
 // base_integrate<true> with the 3-vector updates and the quaternion product q * (cw, dv) as eight packed multiply-adds on
