@@ -184,11 +184,12 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     SV vp, ap;
     {
         const float qdm = K.ml * J.qd;
-        vp.a = leg_prefix(qdm * So.a) + bc.V0.a;
-        vp.l = leg_prefix(qdm * So.l) + bc.V0.l;
-        // a = a_parent + (v x S) qd, v the link's own velocity
-        const V3 ca = qdm * cross(vp.a, So.a);
-        const V3 cl = qdm * cross_add(vp.l, So.a, cross(vp.a, So.l));
+        const SV Sq = {qdm * So.a, qdm * So.l};                      // the joint's velocity S qd: the prefix sum's term, and
+        vp.a = leg_prefix(Sq.a) + bc.V0.a;                             // the second factor of the bias acceleration below
+        vp.l = leg_prefix(Sq.l) + bc.V0.l;
+        // a = a_parent + v x (S qd), v the link's own velocity
+        const V3 ca = cross(vp.a, Sq.a);
+        const V3 cl = cross_add(vp.l, Sq.a, cross(vp.a, Sq.l));
         ap.a = leg_prefix(ca) + bc.A0.a;
         ap.l = leg_prefix(cl) + bc.A0.l;
     }
@@ -357,7 +358,7 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
     {
         SV p0;
         Sym6 Ic0;
-        frame_body(C, bc, h, p0, Ic0);
+        pk3::frame_body_pk(C, bc, h, p0, Ic0);
         // the 28 sums over the env's lanes (21 of the block, 6 of the right-hand side, the FRAME's contact weight), banked
         float t16[16] = {Cn.AA.xx, Cn.AA.yy, Cn.AA.zz, Cn.AA.xy, Cn.AA.xz, Cn.AA.yz, Cn.AL.r0.x, Cn.AL.r0.y,
                          Cn.AL.r0.z, Cn.AL.r1.x, Cn.AL.r1.y, Cn.AL.r1.z, Cn.AL.r2.x, Cn.AL.r2.y, Cn.AL.r2.z, wsumF};

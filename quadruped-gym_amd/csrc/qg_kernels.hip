@@ -194,6 +194,12 @@ template <class T> DEV SVT<T> mul(const Sym6T<T> &A, SVT<T> s) {
 }
 template <class T> DEV void add(Sym6T<T> &a, const Sym6T<T> &b) { add(a.AA, b.AA); add(a.AL, b.AL); add(a.LL, b.LL); }
 namespace pk3 {      // (see above) matrix-vector products on the (x, y) + z split: (xx, yy) and (xz, yz) are pairs, xy enters through the swapped vector
+// six-term dot product of two spatial vectors: the (x, y) products of both halves packed, five instructions for six
+DEV float dot(SV p, SV q) {
+    if (has_literal(p.a) || has_literal(p.l) || has_literal(q.a) || has_literal(q.l)) return ::dot<float>(p, q);
+    const f2 t = __builtin_elementwise_fma(f2{p.l.x, p.l.y}, f2{q.l.x, q.l.y}, f2{p.a.x, p.a.y} * f2{q.a.x, q.a.y});
+    return fmaf(p.l.z, q.l.z, fmaf(p.a.z, q.a.z, t.x)) + t.y;
+}
 // s * (v.y, v.x) + acc in one instruction: the swap of a pair's halves is an op_sel modifier (the compiler folds a broadcast into
 // op_sel, a swap only now and then -- two v_mov otherwise); s rides in the low half of a pair whose high half is never read
 DEV f2 fma_swapped(float s, f2 v, f2 acc) {
@@ -524,6 +530,22 @@ DEV void frame_body(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic
     p0.a = fma3(C.free_damping, c.V0.a, p0.a);
     p0.l = fma3(C.free_damping, c.V0.l, p0.l);
 }
+namespace pk3 {
+// the same with the velocity-product terms as packed cross products (the inertia products keep the plain templates: the compiled-in
+// robot's FRAME inertia is literals, which fold there and would have to be materialised for a packed operand)
+DEV void frame_body_pk(const KModel &C, const BaseCtx &c, float h, SV &p0, Sym6 &Ic0) {
+    Rigid I0 = {C.m0, ld3(C.h0), {C.I0[0], C.I0[1], C.I0[2], C.I0[3], C.I0[4], C.I0[5]}};
+    SV Iv0 = ::mul<float>(I0, c.V0), Ia0 = ::mul<float>(I0, c.A0);
+    p0.a = cross_add(c.V0.l, Iv0.l, cross_add(c.V0.a, Iv0.a, Ia0.a));
+    p0.l = cross_add(c.V0.a, Iv0.l, Ia0.l);
+    Ic0 = sym6_of(I0);
+    float dg = C.free_armature + h * C.free_damping;
+    Ic0.AA.xx += dg; Ic0.AA.yy += dg; Ic0.AA.zz += dg;
+    Ic0.LL.xx += dg; Ic0.LL.yy += dg; Ic0.LL.zz += dg;
+    p0.a = fma3(C.free_damping, c.V0.a, p0.a);
+    p0.l = fma3(C.free_damping, c.V0.l, p0.l);
+}
+}  // namespace pk3
 
 // ------------------------------------------------------------------------------------------
 // one leg: kinematics of fema / shin / foot, recursive Newton-Euler bias forces, ground contact,
