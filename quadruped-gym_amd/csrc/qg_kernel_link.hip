@@ -111,6 +111,7 @@ struct LinkRegs {
     float lo, hi, damping, armature, kp, kv, gear, force_lo, force_hi, act_decay;
     float cpF[3];       // this lane's sample point of the FRAME (one of its twelve; the spare lanes carry none)
     float ml;           // 1 in the lanes that own a link, 0 in the spare lane
+    float fb[8];        // compiled-in robot: the FRAME block's non-zero literals, held in registers for the substep's DPP adds
 };
 // this lane's hinge: lane r < 3 of leg k owns hinge 3k + r; the spare lane shadows hinge 3k + 2 (its copy is never stored)
 struct HingeLane { float q, qd, act, u, sn, cs; };
@@ -281,18 +282,21 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         force = fminf(fmaxf(force, K.force_lo), K.force_hi);
         float dimp = K.damping + (clamped ? 0.f : K.kv * K.gear * K.gear);
         float tau = K.gear * force - K.damping * qd;
-        // soft joint limits: one-sided spring + damper that ramps in with the penetration (continuous torque)
+        // soft joint limits: one-sided spring + damper that ramps in with the penetration (continuous torque).  Written once for
+        // both limits in the frame of the limit that is violated (sg = +1 below the lower one, -1 above the upper one; lo < hi, so at
+        // most one is): t = k pen - b (sg qd) is the torque towards the range, max(t, 0) what is applied (leaving fast: no
+        // pull-back, and the secant k pen / (sg qd) as its damping).  Inside the range pen = 0, hence b = 0, t = 0, nothing added:
+        // no select on "active".  Same products and sums as the two-sided form it replaces (28 -> 19 instructions).
         const float below = K.lo - q, above = q - K.hi;
         const float pen = fmaxf(fmaxf(below, above), 0.f);
         const float bl = C.limit_b * fminf(pen * C.limit_inv_ramp, 1.f);
-        const bool is_below = below > 0.f, is_above = !is_below && above > 0.f;
-        const float spring_b = C.limit_k * below, spring_a = C.limit_k * above;
-        const float tq_b = spring_b - bl * qd, tq_a = spring_a + bl * qd;
-        const bool free_b = tq_b < 0.f, free_a = tq_a < 0.f;          // leaving the limit fast: no pull-back, secant damping
-        const float lim_b = free_b ? 0.f : tq_b, be_b = free_b ? spring_b * rcp(qd) : bl;
-        const float lim_a = free_a ? 0.f : tq_a, be_a = free_a ? -spring_a * rcp(qd) : bl;
-        tau = tau + (is_below ? lim_b : 0.f) - (is_above ? lim_a : 0.f);
-        dimp = dimp + (is_below ? be_b : (is_above ? be_a : 0.f));
+        const float sg = below > above ? 1.f : -1.f;
+        const float sqd = sg * qd;
+        const float spring = C.limit_k * pen;
+        const float tq = spring - bl * sqd;
+        const bool leaving = tq < 0.f;
+        tau = fmaf(sg, fmaxf(tq, 0.f), tau);
+        dimp = dimp + (leaving ? spring * rcp(sqd) : bl);
         Hd_o = Hown + K.armature + h * dimp;
         b_o = tau - tb;
     }
@@ -359,6 +363,13 @@ DEV void substep_link(const KModel &C, float cm, float sm, int r, bool lead_env,
         SV p0;
         Sym6 Ic0;
         pk3::frame_body_pk(C, bc, h, p0, Ic0);
+        // the block's non-zero literals (the FRAME's inertia + armature) come from registers filled once per launch (K.fb): a DPP add
+        // takes no literal, so each of the eight sums below was a DPP move and an add with a literal; with a register operand it is
+        // one v_add_f32_dpp
+        if constexpr (BAKED) {
+            Ic0.AA.xx = K.fb[0]; Ic0.AA.yy = K.fb[1]; Ic0.AA.zz = K.fb[2]; Ic0.LL.xx = K.fb[3]; Ic0.LL.yy = K.fb[4]; Ic0.LL.zz = K.fb[5];
+            Ic0.AL.r0.y = K.fb[6]; Ic0.AL.r1.x = K.fb[7];
+        }
         // the 28 sums over the env's lanes (21 of the block, 6 of the right-hand side, the FRAME's contact weight), banked
         float t16[16] = {Cn.AA.xx, Cn.AA.yy, Cn.AA.zz, Cn.AA.xy, Cn.AA.xz, Cn.AA.yz, Cn.AL.r0.x, Cn.AL.r0.y,
                          Cn.AL.r0.z, Cn.AL.r1.x, Cn.AL.r1.y, Cn.AL.r1.z, Cn.AL.r2.x, Cn.AL.r2.y, Cn.AL.r2.z, wsumF};

@@ -376,12 +376,16 @@ template <class T> DEV void contact_point(V3T<T> r, V3T<T> nl, T zb, T &wsum, V3
 // kept as five numbers until the composite inertia it belongs to is assembled.
 template <class T> struct ContactDampT { T mc, w; V3T<T> P; };
 #define QG_TEMPLATE_T template <class T>
+#define QG_CROSS_ADD(a, b, acc) ((acc) + cross((a), (b)))
 #include "qg_contact_eval.inc"
+#undef QG_CROSS_ADD
 #undef QG_TEMPLATE_T
 namespace pk3 {
 typedef float T;
 #define QG_TEMPLATE_T
+#define QG_CROSS_ADD(a, b, acc) cross_add((a), (b), (acc))          // the packed accumulate form
 #include "qg_contact_eval.inc"
+#undef QG_CROSS_ADD
 #undef QG_TEMPLATE_T
 // add_contact_damping on the pairs the packed code keeps a symmetric block in: (xx, yy), (xz, yz) and the (x, y) halves of AL's rows
 DEV void add_contact_damping(Sym6 &A, float m, float w, V3 r, V3 n) {
