@@ -156,6 +156,64 @@ def test_step_matches_oracle_on_fresh_states(oracle, mapping):
     sim.close()
 
 
+@pytest.mark.parametrize("mapping", ["lane", "quad", "pair", "link"])
+def test_joint_limit_branches_match_oracle(oracle, mapping):
+    """Every branch of the soft joint limits in one batch: hinges below the lower and above the upper limit (0.5 ... 9 degrees
+    outside: inside and beyond the damper's ramp), moving further out, at rest, coming back slowly and LEAVING FAST (the spring
+    would pull back: no torque, secant damping), plus hinges inside the range -- airborne robots, so that nothing but the limits,
+    the servos and the rigid-body terms act.  The one-link-per-lane kernel evaluates both limits in one signed expression
+    (qg_kernel_link.hip), the other kernels side by side: all of them against the oracle's two-sided form."""
+    import torch
+    from quadruped_gym_amd.sim import BatchedSim
+    from helpers import random_state
+    model, task = oracle.default_model(), configure(oracle.default_task(), "A")
+    rng = np.random.default_rng(2026)
+    n = 192
+    qpos = np.zeros((n, 19)); qvel = np.zeros((n, 18))
+    outside = np.deg2rad([0.5, 2.0, 5.0, 9.0])
+    speeds = np.array([-12.0, -3.0, -0.3, 0.0, 0.3, 3.0, 12.0])
+    beyond = 0
+    for e in range(n):
+        q, v = random_state(rng, model, z=1.0, vel=0.3)
+        for j in range(12):
+            lo, hi = model.jnt_range[j][0], model.jnt_range[j][1]
+            kind = (e + 5 * j) % 3                        # 0: inside the range, 1: below the lower limit, 2: above the upper one
+            if kind:
+                d = outside[(e // 3 + j) % 4]
+                q[7 + j] = lo - d if kind == 1 else hi + d
+                v[6 + j] = speeds[(e + 3 * j) % 7]
+                beyond += 1
+        qpos[e], qvel[e] = q, v
+    assert beyond > n * 6
+    qpos, qvel = qpos.astype(np.float32), qvel.astype(np.float32)
+    act = rng.uniform(-0.5, 0.5, (n, 12)).astype(np.float32)
+    nstep = np.zeros(n, np.int32)
+    actions = rng.uniform(-1, 1, (n, 12)).astype(np.float32)
+    b = oracle.Batch(model, task, n)
+    b.set_state(qpos.astype(np.float64), qvel.astype(np.float64), act.astype(np.float64), None, nstep)
+    obs_o, rew_o, done_o, _ = b.step(actions.astype(np.float64))
+    q_o, v_o, a_o, _, n_o = b.get_state()
+    sim = BatchedSim(n, task=configure(_abi.default_task(), "A"))
+    sim.set_mapping(MAPPINGS[mapping])
+    sim.set_state(qpos, qvel, act, None, nstep)
+    dev = torch.device("cuda:0")
+    packed = torch.full((n, 35), float("nan"), device=dev)
+    sim.step_device_packed(torch.from_numpy(actions).to(dev), packed)
+    torch.cuda.synchronize()
+    pk = packed.cpu().numpy()
+    assert np.isfinite(pk).all()
+    t = TOL["A"]
+    q1, v1, a1, _, n1 = sim.get_state()
+    close(q1, q_o, t["qpos"], "qpos")
+    close(v1, v_o, t["qvel"], "qvel")             # the hinge velocities carry the limit torques of four substeps
+    close(a1, a_o, t["act"], "act")
+    mask = np.ones(33, bool); mask[12:15] = False
+    close(pk[:, :33][:, mask], obs_o[:, mask], t["obs"], "obs")
+    close(pk[:, 33], rew_o, t["reward"], "reward")
+    assert np.array_equal(n1, n_o)
+    sim.close()
+
+
 @pytest.mark.parametrize("mapping", ["lane", "quad", "link"])
 def test_generic_variant_matches_oracle_on_a_modified_robot(oracle, mapping):
     """Any model other than the compiled-in default runs the generic kernel variant (tables read from
