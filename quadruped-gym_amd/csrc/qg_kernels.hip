@@ -1270,6 +1270,18 @@ struct LegState {
 
 // Ordered for low register pressure: the leg pass (the widest live set) runs first with only the base context alive;
 // the FRAME terms are built afterwards; sensors go straight to the LDS tile; the rotation is rebuilt at integration.
+// The one-leg-per-lane kernel of the compiled-in robot at ONE wave per SIMD takes the packed prelude / integration of the
+// one-link-per-lane kernel (a lone wave pays per instruction: 2 109 -> 2 072 per substep, 17.74 -> 17.48 us at 8 192 envs, 18.3 -> 18.1
+// at 16 384, sequence form 15.4 -> 15.2); at two waves per SIMD they measured 1.2 % slower and with the generic robot's tables 7 %
+// slower (profiles/r04/quad_packed_prelude_ab.txt), so those keep the plain forms.
+template <bool PKQ> DEV BaseCtx quad_prelude(const KModel &C, const BaseState &B) {
+    if constexpr (PKQ) return pk3::base_prelude_unit(C, B);
+    else return base_prelude<true>(C, B);
+}
+template <bool PKQ> DEV void quad_integrate(const BaseCtx &c, float h, V3 wdot, V3 acl, BaseState &B) {
+    if constexpr (PKQ) pk3::base_integrate_unit(c, h, wdot, acl, B);
+    else base_integrate<true>(c, h, wdot, acl, B);
+}
 // LOWREG: rebuild the base context (cheap) instead of keeping it alive across the leg pass -- pays off once two waves
 // share a SIMD (register cap 256), costs ~2 % when a wave has the register file to itself.
 // BAKED: the compiled-in robot, constants are literals and the lane works in its leg's quarter-turn frame.  Otherwise `C`
@@ -1277,7 +1289,7 @@ struct LegState {
 template <bool BAKED, bool LOWREG>
 DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegState &L, bool want_sensors, float *__restrict__ row, int k, float &zaxis_z) {
     const float h = C.h;
-    const BaseCtx bc0 = base_prelude<true>(C, B);
+    const BaseCtx bc0 = quad_prelude<BAKED && !LOWREG>(C, B);
     V3 gb_keep;
     Sym6 Ic;
     SV fc, Fu;
@@ -1313,7 +1325,7 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
     }
     float x6[6];
     {
-        const BaseCtx bc = LOWREG ? base_prelude<true>(C, B) : bc0;      // rebuilt (cheap) rather than kept alive across the leg pass
+        const BaseCtx bc = LOWREG ? quad_prelude<BAKED && !LOWREG>(C, B) : bc0;      // rebuilt (cheap) rather than kept alive across the leg pass
         SV p0;
         Sym6 Ic0;
         frame_body(C, bc, h, p0, Ic0);
@@ -1376,8 +1388,8 @@ DEV void substep_quad(const KModel &C, float cm, float sm, BaseState &B, LegStat
         L.act[i] = fmaf(L.u[i] - L.act[i], link_of<BAKED>(C, k, i).act_decay, L.act[i]);
     }
     {
-        const BaseCtx bc = LOWREG ? base_prelude<true>(C, B) : bc0;
-        base_integrate<true>(bc, h, wdot, acl, B);
+        const BaseCtx bc = LOWREG ? quad_prelude<BAKED && !LOWREG>(C, B) : bc0;
+        quad_integrate<BAKED && !LOWREG>(bc, h, wdot, acl, B);
     }
 }
 
